@@ -1,0 +1,141 @@
+/*
+ * zkmi.h -- C ABI of libzkmi.so: the MI355X (gfx950) multilinear sumcheck prover.
+ *
+ * Drop-in boundary for ONE path of the webdott/zk Rust workspace: the per-round
+ * round-polynomial reduction + fold of a multilinear-extension table over BN254 Fq
+ * (SURVEY.md section 8).  The reference has no FFI of its own: each entry
+ * point below names the Rust item (file:line under /root/reference) whose work it
+ * replaces; INTEGRATION.md shows the `extern "C"` shim crate a maintainer would add.
+ *
+ * Conventions
+ *  - Field elements cross the boundary as 4 x u64 little-endian limbs of a*R mod p
+ *    (R = 2^256, fully reduced) -- ark-ff's in-memory form of `Fp256<MontBackend>` --
+ *    unless a name says le32 (canonical value, 32 little-endian bytes =
+ *    `into_bigint().to_bytes_le()`).
+ *  - Every function returns a zk_status; where the reference panics, a non-zero code is
+ *    returned instead (the Rust shim turns it back into panic!).  Verifiers' `bool`
+ *    results come back through an int* out-parameter.
+ *  - All output buffers are caller-allocated.  Handles are opaque, not thread-safe; one
+ *    prove in flight per context.  Tables handed to a prover are left unmodified.
+ *  - There is NO CPU fallback: every compute entry point needs a gfx950 device.
+ */
+#ifndef ZKMI_H
+#define ZKMI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+#if defined(__GNUC__)
+#pragma GCC visibility push(default) /* the library is built -fvisibility=hidden: only this ABI is exported */
+#endif
+
+typedef enum zk_status {
+    ZK_OK = 0,
+    ZK_E_NOT_POW2 = 1,     /* evaluation_form.rs:23-27  "length is not a power of two" */
+    ZK_E_POINTS_LEN = 2,   /* evaluation_form.rs:197-199, product_polynomial.rs:32-34 */
+    ZK_E_LEN_MISMATCH = 3, /* product_polynomial.rs:15-19, sum_polynomial.rs:15-19, evaluation_form.rs:244-246 */
+    ZK_E_LAYER_OOB = 4,    /* circuit.rs:83-85, 131-133 */
+    ZK_E_DEGREE = 5,       /* sum polynomial not 2 terms x 2 factors (sumcheck/src/prover.rs:90-107) */
+    ZK_E_ALLOC = 6,
+    ZK_E_HIP = 7,          /* a HIP runtime call failed; zk_last_error() has the text */
+    ZK_E_ARG = 8,          /* NULL pointer / bad argument */
+    ZK_E_NO_DEVICE = 9,    /* no gfx950 device: the library refuses to run (no CPU path) */
+    ZK_E_COMM = 10         /* collective (RCCL) failure */
+} zk_status;
+
+typedef struct zk_ctx zk_ctx;               /* one GPU: device, stream, scratch */
+typedef struct zk_mle zk_mle;               /* MultiLinearPolynomial<T> as a device-resident table */
+typedef struct zk_transcript zk_transcript; /* fiat_shamir::Transcript<T> (host) */
+
+const char *zk_strerror(int status);
+const char *zk_last_error(const zk_ctx *ctx); /* text of the last ZK_E_HIP / ZK_E_COMM on this context */
+const char *zk_version(void);
+
+/* ---- context ------------------------------------------------------------------------- */
+int zk_ctx_create(int device_id, zk_ctx **out);
+void zk_ctx_destroy(zk_ctx *ctx);
+/* the HIP stream (hipStream_t) every kernel of this context is launched on */
+void *zk_ctx_stream(zk_ctx *ctx);
+int zk_ctx_synchronize(zk_ctx *ctx);
+
+/* ---- fiat_shamir::Transcript (fiat_shamir/src/transcript.rs:11-42), host-side -------- */
+zk_transcript *zk_transcript_new(void);                                    /* Transcript::new   :12-17 */
+zk_transcript *zk_transcript_clone(const zk_transcript *t);                /* the sponge state is plain data */
+void zk_transcript_free(zk_transcript *t);
+int zk_transcript_append(zk_transcript *t, const uint8_t *data, size_t len); /* append         :20-22 */
+int zk_transcript_sample_challenge(zk_transcript *t, uint64_t out_mont[4]);  /* sample_challenge :28-36 */
+int zk_transcript_sample_n_challenges(zk_transcript *t, size_t n, uint64_t *out_mont); /* :39-41 */
+int zk_transcript_peek_digest(const zk_transcript *t, uint8_t out[32]);    /* Keccak256(all bytes so far) */
+
+/* ---- MultiLinearPolynomial (polynomials/src/multilinear_polynomial/evaluation_form.rs) */
+/* MultiLinearPolynomial::new :22-32 -- copies `len` elements host -> device. */
+int zk_mle_upload_mont(zk_ctx *ctx, const uint64_t *limbs, size_t len, zk_mle **out);
+int zk_mle_upload_le32(zk_ctx *ctx, const uint8_t *bytes, size_t len, zk_mle **out);
+/* borrow `len` elements of device memory the caller owns (Montgomery limbs); never freed by the library */
+int zk_mle_wrap_device(zk_ctx *ctx, void *device_ptr, size_t len, zk_mle **out);
+/* synthetic table generated on device: entry j = splitmix64 stream `seed`,
+ * draws 4(first+j)+1 .. +4, little-endian 256 bits, mod p, to Montgomery.  No reference counterpart. */
+int zk_mle_generate(zk_ctx *ctx, uint64_t seed, uint64_t first, size_t len, zk_mle **out);
+int zk_mle_clone(const zk_mle *src, zk_mle **out);                          /* #[derive(Clone)] :16 */
+void zk_mle_free(zk_mle *m);
+size_t zk_mle_len(const zk_mle *m);
+void *zk_mle_device_ptr(const zk_mle *m);
+int zk_mle_download_mont(const zk_mle *m, uint64_t *out_limbs);             /* get_evaluation_points :155-157 */
+int zk_mle_to_le32(const zk_mle *m, uint8_t *out_bytes);                    /* to_bytes :225-234 (32*len bytes) */
+/* partially_evaluate((var, r)) :163-192 with the pairing of get_y1_y2_indexes :45-80 -> new table of len/2 */
+int zk_mle_partially_evaluate(const zk_mle *m, size_t var, const uint64_t r_mont[4], zk_mle **out);
+/* evaluate(&[Option<T>]) :194-223; has[i] != 0 means Some(vals[i]).  npts must equal log2(len). */
+int zk_mle_evaluate(const zk_mle *m, const uint8_t *has, const uint64_t *vals_mont, size_t npts, zk_mle **out);
+int zk_mle_evaluation_sum(const zk_mle *m, uint64_t out_mont[4]);           /* evaluation_sum :236-238 */
+/* the MLE-branch round reduction of generate_round_polys (sumcheck/src/prover.rs:108-116):
+ * out[0..4) = sum of the first half, out[4..8) = sum of the second half.  len >= 2. */
+int zk_mle_round_sums(const zk_mle *m, uint64_t out_mont[8]);
+
+/* ---- sumcheck prover (sumcheck/src/prover.rs) ----------------------------------------- */
+/* SumcheckProver::generate_sumcheck_proof :158-173 when `transcript` is NULL or
+ * absorb_table != 0 (a fresh transcript absorbs to_bytes() of the table first); with a
+ * caller transcript and absorb_table == 0 it is generate_round_polys :45-155 on the MLE branch.
+ *   claim_out      SumCheckProof.initial_claim_sum
+ *   coeffs_out     round_polys, n x 2 coefficients ascending (n = log2 len)
+ *   challenges_out n challenges (the reference discards them; may be NULL) */
+int zk_sumcheck_prove_mle(zk_ctx *ctx, const zk_mle *poly, int absorb_table, zk_transcript *transcript,
+                          uint64_t claim_out[4], uint64_t *coeffs_out, uint64_t *challenges_out);
+/* SumcheckProver::generate_proof_for_partial_verify :175-190 for
+ * SumPolynomial[ ProductPolynomial[t0,t1], ProductPolynomial[t2,t3] ] -- the only shape the
+ * reference's degree-2 branch accepts and the GKR layer relation.
+ *   coeffs_out n x 3 coefficients, challenges_out n random points.  The claim is copied into
+ *   the proof unchecked, as in the reference (:185). */
+int zk_sumcheck_prove_sum2x2(zk_ctx *ctx, zk_mle *const tables[4], const uint64_t claim_mont[4],
+                             zk_transcript *transcript, uint64_t *coeffs_out, uint64_t *challenges_out);
+
+/* ---- sumcheck verifier (sumcheck/src/verifier.rs) -- the parity harness ---------------- */
+/* partial_verify :29-62 (host only). */
+int zk_sumcheck_partial_verify(const uint64_t claim_mont[4], const uint64_t *coeffs, size_t n_rounds,
+                               size_t coeffs_per_round, zk_transcript *transcript, int *ok_out,
+                               uint64_t final_claim_out[4], uint64_t *challenges_out);
+/* verify_proof :64-94: table absorb + partial_verify + the oracle check (device evaluate). */
+int zk_sumcheck_verify_mle(zk_ctx *ctx, const zk_mle *poly, const uint64_t claim_mont[4], const uint64_t *coeffs,
+                           size_t n_rounds, int *ok_out);
+
+/* ---- measurement hooks (no reference counterpart) ------------------------------------- */
+enum { ZK_K_ROUND_SUMS = 0, ZK_K_FOLD_SUMS = 1, ZK_K_FOLD = 2, ZK_K_EVAL3 = 3, ZK_K_FOLD4_EVAL3 = 4, ZK_K_COUNT = 8 };
+/* per-kernel HIP-event timing of the launches made by the provers on this context */
+int zk_prof_enable(zk_ctx *ctx, int on);
+int zk_prof_reset(zk_ctx *ctx);
+/* totals since the last reset: launches, elapsed ms (HIP events on the context stream) and
+ * ALGORITHMIC bytes (fold 48 B/input entry, round sums 32 B/entry, ...) */
+int zk_prof_read(zk_ctx *ctx, int kernel, uint64_t *launches, double *ms, uint64_t *alg_bytes);
+/* Montgomery-multiply throughput probe: `iters` dependent multiplies per lane on `blocks` x 256
+ * lanes; returns elapsed ms.  Used for the int32-ALU roofline figure. */
+int zk_bench_modmul(zk_ctx *ctx, int blocks, int iters, double *ms_out);
+
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZKMI_H */

@@ -170,11 +170,22 @@ API int orc_sumcheck_prove(const uint64_t *table, size_t len, uint64_t claim_out
     }
     mle_free(&m); return rc;
 }
-/* the unmodified reference entry point, for timing the CPU baseline */
-API int orc_sumcheck_prove_timed(const uint64_t *table, size_t len, uint64_t claim_out[4]) {
-    mle_t m = {(fq_t *)table, len}; sumcheck_proof_t p;
-    int rc = sumcheck_generate_proof(&p, &m); if (rc) return rc;
-    memcpy(claim_out, p.initial_claim_sum.l, 32); sumcheck_proof_free(&p); return 0;
+/* for timing the CPU baseline: absorb != 0 is the unmodified reference entry point
+ * generate_sumcheck_proof (prover.rs:158-173); absorb == 0 runs only generate_round_polys
+ * (prover.rs:45-155) on a fresh transcript -- the round loop the GPU figure is quoted on. */
+API int orc_sumcheck_prove_timed(const uint64_t *table, size_t len, int absorb, uint64_t claim_out[4]) {
+    mle_t m = {(fq_t *)table, len};
+    if (absorb) {
+        sumcheck_proof_t p;
+        int rc = sumcheck_generate_proof(&p, &m); if (rc) return rc;
+        memcpy(claim_out, p.initial_claim_sum.l, 32); sumcheck_proof_free(&p); return 0;
+    }
+    transcript_t tr; transcript_new(&tr);
+    unipoly_t *rp; fq_t *ch; size_t nr;
+    int rc = sumcheck_generate_round_polys(NULL, &m, &tr, &rp, &ch, &nr); if (rc) return rc;
+    if (nr) { fq_t s; fq_add(&s, &rp[0].c[0], &rp[0].c[0]); fq_add(&s, &s, &rp[0].c[1]); memcpy(claim_out, s.l, 32); }
+    for (size_t k = 0; k < nr; ++k) uni_free(&rp[k]);
+    free(rp); free(ch); return 0;
 }
 static int mk_proof(sumcheck_proof_t *p, const uint64_t claim[4], const uint64_t *coeffs, size_t n_rounds, size_t ncoef) {
     memcpy(p->initial_claim_sum.l, claim, 32);

@@ -1,0 +1,245 @@
+"""GPU parity tests: the HIP path (through the C ABI of libzkmi.so) against the CPU oracle
+(oracle/liboracle.so) and the committed golden vectors.  Bit-exact: integer field arithmetic.
+Run on an MI355X:  python -m pytest tests -m gpu"""
+import random
+
+import numpy as np
+import pytest
+
+import golden_lib as G
+import oracle_lib as O
+import zk_amd
+from zk_amd import MultiLinearPolynomial as MLE
+
+pytestmark = pytest.mark.gpu
+
+SEED = 0x5EED0000
+P = O.P
+
+
+def rand_table(n, seed):
+    """full-range values incl. the edge values 0, 1, p-1, p-2 sprinkled in"""
+    rng = random.Random(seed)
+    vals = [rng.randrange(P) for _ in range(n)]
+    for k, v in enumerate([0, 1, P - 1, P - 2, (P - 1) // 2, 2**253]):
+        if k < n:
+            vals[rng.randrange(n)] = v
+    return vals
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    return zk_amd.default_context()
+
+
+def test_native_library_is_loaded(ctx):
+    assert zk_amd.lib().zk_version().startswith(b"zkmi")
+    assert ctx.stream != 0
+
+
+def test_upload_download_roundtrip_and_to_bytes(ctx):
+    for n in (1, 2, 8, 64, 1 << 12):
+        vals = rand_table(n, n)
+        t = O.ints_to_mont(vals)
+        m = MLE(t)
+        assert len(m) == n and m.number_of_variables() == n.bit_length() - 1
+        assert np.array_equal(m.get_evaluation_points(), t)
+        assert m.to_bytes() == O.mle_to_bytes(t) == O.pyref.to_bytes(vals)
+        # le32 upload (reduces mod p) and back
+        m2 = MLE.from_le32(m.to_bytes())
+        assert np.array_equal(m2.get_evaluation_points(), t)
+    # non-canonical LE32 input (>= p, up to 2^256-1) is reduced like from_le_bytes_mod_order
+    raw = [P, P + 5, 2**256 - 1, 4 * P + 3]
+    m3 = MLE.from_le32(b"".join(v.to_bytes(32, "little") for v in raw))
+    assert O.mont_to_ints(m3.get_evaluation_points()) == [v % P for v in raw]
+
+
+def test_new_rejects_non_power_of_two(ctx):
+    for n in (3, 5, 6, 12, 1000):
+        with pytest.raises(zk_amd.ZkError) as ei:
+            MLE(np.zeros((n, 4), dtype=np.uint64))
+        assert ei.value.status == 1            # evaluation_form.rs:23-27
+    with pytest.raises(zk_amd.ZkError):
+        MLE(np.zeros((0, 4), dtype=np.uint64))
+
+
+def test_generate_matches_oracle(ctx):
+    for first, n in ((0, 1), (0, 256), (12345, 4096), (2**33 + 7, 64)):
+        m = MLE.generate(SEED + 3, n, first=first)
+        assert np.array_equal(m.get_evaluation_points(), O.gen_table(SEED + 3, first, n))
+
+
+def test_reference_fold_vectors(ctx):
+    # evaluation_form.rs:366-419
+    poly4 = [0, 0, 0, 0, 0, 4, 0, 4, 0, 0, 3, 3, 5, 9, 8, 12]
+    poly3 = [0, 0, 0, 3, 0, 0, 2, 5]
+    m4, m3 = MLE(O.ints_to_mont(poly4)), MLE(O.ints_to_mont(poly3))
+    f = O.fq1
+    assert O.mont_to_ints(m4.evaluate([f(4), f(2), f(6), f(1)]).get_evaluation_points()) == [120]
+    assert O.mont_to_ints(m4.evaluate([f(4), None, None, None]).get_evaluation_points()) == [0, 0, 12, 12, 20, 24, 32, 36]
+    assert O.mont_to_ints(m3.evaluate([None, None, f(3)]).get_evaluation_points()) == [0, 9, 0, 11]
+    with pytest.raises(zk_amd.ZkError) as ei:   # :197-199
+        m3.evaluate([f(1), f(2)])
+    assert ei.value.status == 2
+    with pytest.raises(zk_amd.ZkError):
+        m3.partially_evaluate((3, f(1)))
+
+
+@pytest.mark.parametrize("log_n", [1, 2, 3, 7, 12, 16])
+def test_partially_evaluate_every_variable_vs_oracle(ctx, log_n):
+    n = 1 << log_n
+    t = O.ints_to_mont(rand_table(n, 100 + log_n)) if log_n <= 12 else O.gen_table(SEED + 9, 0, n)
+    m = MLE(t)
+    rng = random.Random(log_n)
+    variables = range(log_n) if log_n <= 7 else (0, 1, log_n // 2, log_n - 1)
+    for var in variables:
+        for rv in (0, 1, P - 1, rng.randrange(P)):
+            r = O.fq1(rv)
+            got = m.partially_evaluate((var, r)).get_evaluation_points()
+            assert np.array_equal(got, O.mle_partially_evaluate(t, var, r)), (var, rv)
+
+
+def test_evaluate_mixed_points_vs_oracle(ctx):
+    rng = random.Random(77)
+    for log_n in (3, 6, 10):
+        t = O.ints_to_mont(rand_table(1 << log_n, 200 + log_n))
+        m = MLE(t)
+        for trial in range(4):
+            pts = [None if rng.random() < 0.4 else O.fq1(rng.randrange(P)) for _ in range(log_n)]
+            got = m.evaluate(pts).get_evaluation_points()
+            assert np.array_equal(got, O.mle_evaluate(t, pts))
+        full = [O.fq1(rng.randrange(P)) for _ in range(log_n)]
+        assert np.array_equal(m.evaluate(full).get_evaluation_points(), O.mle_evaluate(t, full))
+
+
+@pytest.mark.parametrize("log_n", [1, 2, 5, 9, 14, 18])
+def test_sums_vs_oracle(ctx, log_n):
+    n = 1 << log_n
+    t = O.gen_table(SEED + 11, 0, n)
+    m = MLE(t)
+    assert list(m.evaluation_sum()) == list(O.mle_sum(t))
+    e = m.round_sums()
+    assert list(e[0]) == list(O.mle_sum(t[: n // 2])) and list(e[1]) == list(O.mle_sum(t[n // 2:]))
+    # worst case for the carry chains: every entry p-1
+    tm = O.ints_to_mont([P - 1] * min(n, 4096))
+    mm = MLE(tm)
+    assert O.mont_to_ints(mm.evaluation_sum()) == [(P - 1) * len(tm) % P]
+
+
+@pytest.mark.parametrize("case", G.vectors()["sumcheck"], ids=lambda c: c["name"])
+def test_sumcheck_golden(ctx, case):
+    table = G.case_table(case)
+    poly = MLE(table)
+    proof, ch = zk_amd.SumcheckProver.generate_sumcheck_proof(poly, return_challenges=True)
+    assert G.le32_of(proof.initial_claim_sum) == [case["initial_claim_sum"]]
+    assert [G.le32_of(g) for g in proof.round_polys] == case["round_polys"]
+    assert G.le32_of(ch) == case["challenges"]
+    # the prover leaves the caller's table untouched (it borrows &MLE, prover.rs:158)
+    assert np.array_equal(poly.get_evaluation_points(), table)
+    # accepted by the device verifier AND by the CPU oracle's verifier
+    assert zk_amd.SumcheckVerifier.verify_proof(poly, proof)
+    assert O.sumcheck_verify(table, proof.initial_claim_sum, proof.round_polys)
+
+
+@pytest.mark.parametrize("log_n", [0, 1, 2, 3, 5, 8, 11, 15, 18])
+def test_sumcheck_vs_oracle_random_full_range(ctx, log_n):
+    n = 1 << log_n
+    table = O.ints_to_mont(rand_table(n, 300 + log_n)) if log_n <= 11 else O.gen_table(SEED + 21, 5, n)
+    poly = MLE(table)
+    proof, ch = zk_amd.SumcheckProver.generate_sumcheck_proof(poly, return_challenges=True)
+    oclaim, ocoeffs, och = O.sumcheck_prove(table)
+    assert list(proof.initial_claim_sum) == list(oclaim)
+    assert np.array_equal(proof.round_polys, ocoeffs)
+    assert np.array_equal(ch, och)
+    ok = zk_amd.SumcheckVerifier.verify_proof(poly, proof)
+    assert ok == (log_n > 0)                    # zero rounds => false (verifier.rs:86-91)
+    assert ok == O.sumcheck_verify(table, oclaim, ocoeffs)
+
+
+def test_sumcheck_reference_fail_vector_and_tampering(ctx):
+    # sumcheck_protocol.rs:52-82: the hand-forged proof is rejected
+    bad_table = MLE(O.ints_to_mont([0, 0, 0, 3, 0, 0, 2, 65]))
+    forged = zk_amd.SumCheckProof(O.fq1(10), np.stack([O.ints_to_mont([3, 7]), O.ints_to_mont([9, 10]), O.ints_to_mont([10, 97])]))
+    assert not zk_amd.SumcheckVerifier.verify_proof(bad_table, forged)
+    table = O.gen_table(SEED + 5, 0, 1 << 9)
+    poly = MLE(table)
+    proof = zk_amd.SumcheckProver.generate_sumcheck_proof(poly)
+    assert zk_amd.SumcheckVerifier.verify_proof(poly, proof)
+    for rnd, coef in ((0, 0), (4, 1), (8, 0)):
+        rp = proof.round_polys.copy()
+        rp[rnd, coef] = O.fq1(O.mont_to_ints(rp[rnd, coef])[0] + 1)
+        assert not zk_amd.SumcheckVerifier.verify_proof(poly, zk_amd.SumCheckProof(proof.initial_claim_sum, rp))
+    wrong_claim = O.fq1(O.mont_to_ints(proof.initial_claim_sum)[0] + 1)
+    assert not zk_amd.SumcheckVerifier.verify_proof(poly, zk_amd.SumCheckProof(wrong_claim, proof.round_polys))
+    # a proof for one table does not verify against another
+    other = MLE.generate(SEED + 6, 1 << 9)
+    assert not zk_amd.SumcheckVerifier.verify_proof(other, proof)
+
+
+def test_generate_round_polys_on_caller_transcript(ctx):
+    table = O.gen_table(SEED + 31, 0, 1 << 10)
+    poly = MLE(table)
+    tr = zk_amd.Transcript()
+    tr.append(poly.to_bytes())
+    claim, coeffs, ch = zk_amd.SumcheckProver.generate_round_polys(poly, tr)
+    oclaim, ocoeffs, och = O.sumcheck_prove(table)
+    assert list(claim) == list(oclaim) and np.array_equal(coeffs, ocoeffs) and np.array_equal(ch, och)
+
+
+def _sum_poly(tabs):
+    m = [MLE(t) for t in tabs]
+    return zk_amd.SumPolynomial([zk_amd.ProductPolynomial([m[0], m[1]]), zk_amd.ProductPolynomial([m[2], m[3]])]), m
+
+
+@pytest.mark.parametrize("case", G.vectors()["sum2x2"], ids=lambda c: c["name"])
+def test_sum2x2_golden(ctx, case):
+    tabs = [O.gen_table(s, 0, 1 << case["log_n"]) for s in case["seeds"]]
+    f, mles = _sum_poly(tabs)
+    tr = zk_amd.Transcript()
+    tr.append(case["transcript_prefix"].encode())
+    proof, pts = zk_amd.SumcheckProver.generate_proof_for_partial_verify(O.fq1(G.unhex(case["claim"])), f, tr)
+    assert [G.le32_of(g) for g in proof.round_polys] == case["round_polys"]
+    assert G.le32_of(pts) == case["challenges"]
+    for m, t in zip(mles, tabs):
+        assert np.array_equal(m.get_evaluation_points(), t)   # inputs untouched
+    tv = zk_amd.Transcript()
+    tv.append(case["transcript_prefix"].encode())
+    ok, final, ch = zk_amd.SumcheckVerifier.partial_verify(proof, tv)
+    assert ok and G.le32_of(final) == [case["final_claim"]]
+
+
+def test_partial_sumcheck_reference_vector(ctx):
+    # sumcheck_protocol.rs:85-111: 2 x (e1 * e2), claim 12
+    e1, e2 = O.ints_to_mont([0, 0, 0, 2]), O.ints_to_mont([0, 0, 0, 3])
+    f, _ = _sum_poly([e1, e2, e1, e2])
+    proof, pts = zk_amd.SumcheckProver.generate_proof_for_partial_verify(O.fq1(12), f, zk_amd.Transcript())
+    assert zk_amd.SumcheckVerifier.partial_verify(proof, zk_amd.Transcript())[0]
+    ocoeffs, och = O.sumcheck_prove_sum([[e1, e2], [e1, e2]], O.fq1(12), O.OTranscript())
+    assert np.array_equal(proof.round_polys, ocoeffs) and np.array_equal(pts, och)
+
+
+@pytest.mark.parametrize("log_n", [1, 2, 4, 7, 10, 13])
+def test_sum2x2_vs_oracle_random_full_range(ctx, log_n):
+    n = 1 << log_n
+    tabs = [O.ints_to_mont(rand_table(n, 400 + 10 * log_n + k)) if log_n <= 10 else O.gen_table(SEED + 40 + k, 0, n)
+            for k in range(4)]
+    f, _ = _sum_poly(tabs)
+    claim = O.fq1(12345)                 # the prover copies the claim unchecked (prover.rs:185)
+    tr, otr = zk_amd.Transcript(), O.OTranscript()
+    tr.append(b"layer-7")
+    otr.append(b"layer-7")
+    proof, pts = zk_amd.SumcheckProver.generate_proof_for_partial_verify(claim, f, tr)
+    ocoeffs, och = O.sumcheck_prove_sum([[tabs[0], tabs[1]], [tabs[2], tabs[3]]], claim, otr)
+    assert np.array_equal(proof.round_polys, ocoeffs)
+    assert np.array_equal(pts, och)
+    assert tr.peek_digest() == otr.peek_digest()   # transcripts end in the same state
+
+
+def test_sum2x2_shape_errors(ctx):
+    a, b = MLE(O.gen_table(1, 0, 8)), MLE(O.gen_table(2, 0, 4))
+    with pytest.raises(zk_amd.ZkError):
+        zk_amd.ProductPolynomial([a, b])
+    one_term = zk_amd.SumPolynomial([zk_amd.ProductPolynomial([a, a])])
+    with pytest.raises(zk_amd.ZkError) as ei:      # F9: degree() = 1 cannot be interpolated at [0,1,2]
+        zk_amd.SumcheckProver.generate_proof_for_partial_verify(O.fq1(0), one_term, zk_amd.Transcript())
+    assert ei.value.status == 5

@@ -1,0 +1,62 @@
+"""Device context: one GPU, one HIP stream, scratch buffers (zk_ctx in include/zkmi.h)."""
+from __future__ import annotations
+
+import ctypes as C
+
+from ._lib import check, lib
+
+KERNELS = {"round_sums": 0, "fold_sums": 1, "fold": 2, "eval3": 3, "fold4_eval3": 4}
+
+
+class Context:
+    def __init__(self, device_id: int = 0):
+        h = C.c_void_p()
+        check(lib().zk_ctx_create(device_id, C.byref(h)))
+        self.h = h
+        self.device_id = device_id
+
+    @property
+    def stream(self) -> int:
+        """hipStream_t (as int) every kernel of this context is launched on."""
+        return lib().zk_ctx_stream(self.h) or 0
+
+    def synchronize(self):
+        check(lib().zk_ctx_synchronize(self.h), self.h)
+
+    # ---- measurement hooks
+    def prof_enable(self, on: bool = True):
+        check(lib().zk_prof_enable(self.h, int(on)))
+
+    def prof_reset(self):
+        check(lib().zk_prof_reset(self.h))
+
+    def prof_read(self, kernel: str):
+        n, ms, b = C.c_uint64(), C.c_double(), C.c_uint64()
+        check(lib().zk_prof_read(self.h, KERNELS[kernel], C.byref(n), C.byref(ms), C.byref(b)))
+        return {"launches": n.value, "ms": ms.value, "alg_bytes": b.value}
+
+    def bench_modmul(self, blocks: int, iters: int) -> float:
+        ms = C.c_double()
+        check(lib().zk_bench_modmul(self.h, blocks, iters, C.byref(ms)), self.h)
+        return ms.value
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().zk_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default = None
+
+
+def default_context() -> Context:
+    global _default
+    if _default is None:
+        _default = Context(0)
+    return _default

@@ -1,0 +1,30 @@
+// kernels.h -- host-callable launchers of the gfx950 kernels in kernels.hip.
+// All pointers are device pointers to 32-byte Montgomery elements; `r` is a challenge as
+// 4 x u64 Montgomery limbs (passed to the kernel by value: it lands in SGPRs).
+// Launchers that produce per-block partial sums return the number of blocks launched;
+// `partials` must hold kMaxBlocks * 3 elements.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace zkk {
+
+// 256 CUs x 8 blocks of 256 threads: enough waves to cover HBM latency, few enough partials
+// that the second stage stays a single block (cdna_hip_programming.md, Guideline 11)
+static constexpr int kMaxBlocks = 2048;
+
+int launch_round_sums(const void* T, size_t half, void* partials, hipStream_t st);
+int launch_fold_sums(const void* src, void* dst, size_t q, const uint64_t r[4], void* partials, hipStream_t st);
+void launch_fold_var(const void* src, void* dst, size_t n_out, int log_s, const uint64_t r[4], hipStream_t st);
+void launch_reduce_partials(const void* partials, int nblocks, int ns, void* out, hipStream_t st);
+int launch_sum_all(const void* T, size_t n, void* partials, hipStream_t st);
+int launch_eval3(const void* const t[4], size_t half, void* partials, hipStream_t st);
+int launch_fold4_eval3(const void* const s[4], void* const d[4], size_t q, const uint64_t r[4], void* partials, hipStream_t st);
+void launch_fold4(const void* const s[4], void* const d[4], size_t half, const uint64_t r[4], hipStream_t st);
+void launch_from_le32(const void* in, void* out, size_t n, hipStream_t st);
+void launch_to_le32(const void* in, void* out, size_t n, hipStream_t st);
+void launch_generate(void* out, uint64_t seed, uint64_t first, size_t n, hipStream_t st);
+void launch_modmul_probe(void* io, int blocks, int iters, hipStream_t st);
+
+} // namespace zkk

@@ -1,0 +1,704 @@
+// zkmi.cpp -- the C ABI of include/zkmi.h: contexts, device-resident tables, the host
+// transcript and the sumcheck prover round loops that drive the gfx950 kernels.
+//
+// Round loop: reduce_k -> host: coefficients, Keccak absorb, challenge r_k ->
+// fold_k fused with reduce_{k+1}.  The table never leaves HBM; per round (d+1) x 32 B come
+// back to the host and 32 B (the challenge) go out as a kernel argument.
+#include "../../include/zkmi.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "fq_host.hpp"
+#include "keccak_host.hpp"
+#include "kernels.h"
+
+using zkh::Fq;
+
+namespace {
+constexpr size_t kElem = 32;
+constexpr size_t kChunkElems = (size_t)1 << 21; // 64 MiB staging chunks for byte conversion
+
+inline bool is_pow2(size_t n) { return n && !(n & (n - 1)); }
+inline unsigned ilog2(size_t n) {
+    unsigned k = 0;
+    while (n > 1) { n >>= 1; ++k; }
+    return k;
+}
+} // namespace
+
+struct zk_transcript {
+    zkh::Keccak256 hasher;
+    void append(const uint8_t* d, size_t n) { hasher.update(d, n); }
+    void append_fq(const Fq& v) {
+        uint8_t b[32];
+        zkh::to_le32(v, b);
+        hasher.update(b, 32);
+    }
+    Fq sample() { // transcript.rs:28-36
+        uint8_t h[32];
+        hasher.peek(h);
+        hasher.update(h, 32);
+        return zkh::from_le32_mod_order(h);
+    }
+};
+
+struct ProfSlot { int kernel; hipEvent_t a, b; uint64_t bytes; };
+
+struct zk_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    void* partials = nullptr;   // kMaxBlocks * 3 elements
+    void* sums_dev = nullptr;   // 3 elements
+    uint64_t* sums_host = nullptr; // pinned, 3 elements
+    void* work[2] = {nullptr, nullptr};
+    size_t work_cap[2] = {0, 0}; // bytes
+    void* stage = nullptr;       // kChunkElems elements
+    std::string err;
+    bool prof_on = false;
+    std::vector<ProfSlot> prof_pending;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_free;
+    uint64_t prof_launches[ZK_K_COUNT] = {0};
+    double prof_ms[ZK_K_COUNT] = {0};
+    uint64_t prof_bytes[ZK_K_COUNT] = {0};
+};
+
+struct zk_mle {
+    zk_ctx* ctx;
+    void* d;
+    size_t len;
+    bool owned;
+};
+
+#define HIPCHK(ctx, call)                                                                           \
+    do {                                                                                            \
+        hipError_t e_ = (call);                                                                     \
+        if (e_ != hipSuccess) {                                                                     \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                         \
+            return ZK_E_HIP;                                                                        \
+        }                                                                                           \
+    } while (0)
+
+namespace {
+
+int set_device(zk_ctx* c) { HIPCHK(c, hipSetDevice(c->device)); return ZK_OK; }
+
+int ensure_work(zk_ctx* c, int which, size_t bytes) {
+    if (c->work_cap[which] >= bytes) return ZK_OK;
+    if (c->work[which]) { HIPCHK(c, hipFree(c->work[which])); c->work[which] = nullptr; c->work_cap[which] = 0; }
+    HIPCHK(c, hipMalloc(&c->work[which], bytes));
+    c->work_cap[which] = bytes;
+    return ZK_OK;
+}
+int ensure_stage(zk_ctx* c) {
+    if (!c->stage) HIPCHK(c, hipMalloc(&c->stage, kChunkElems * kElem));
+    return ZK_OK;
+}
+
+// ---- profiling brackets -------------------------------------------------------------------
+struct ProfScope {
+    zk_ctx* c;
+    bool active;
+    ProfSlot slot;
+    ProfScope(zk_ctx* ctx, int kernel, uint64_t bytes) : c(ctx), active(ctx->prof_on) {
+        if (!active) return;
+        slot.kernel = kernel;
+        slot.bytes = bytes;
+        if (!c->prof_free.empty()) {
+            slot.a = c->prof_free.back().first;
+            slot.b = c->prof_free.back().second;
+            c->prof_free.pop_back();
+        } else if (hipEventCreate(&slot.a) != hipSuccess || hipEventCreate(&slot.b) != hipSuccess) {
+            active = false;
+            return;
+        }
+        (void)hipEventRecord(slot.a, c->stream);
+    }
+    ~ProfScope() {
+        if (!active) return;
+        (void)hipEventRecord(slot.b, c->stream);
+        c->prof_pending.push_back(slot);
+    }
+};
+// call only after the stream has been synchronized
+void prof_collect(zk_ctx* c) {
+    for (auto& s : c->prof_pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
+            c->prof_launches[s.kernel] += 1;
+            c->prof_ms[s.kernel] += ms;
+            c->prof_bytes[s.kernel] += s.bytes;
+        }
+        c->prof_free.emplace_back(s.a, s.b);
+    }
+    c->prof_pending.clear();
+}
+
+// second stage + device->host of ns sums; blocks until they are on the host
+int fetch_sums(zk_ctx* c, int nblocks, int ns, Fq* out) {
+    zkk::launch_reduce_partials(c->partials, nblocks, ns, c->sums_dev, c->stream);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(c->sums_host, c->sums_dev, (size_t)ns * kElem, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int s = 0; s < ns; ++s) out[s] = zkh::load(c->sums_host + 4 * s);
+    return ZK_OK;
+}
+
+int new_mle(zk_ctx* c, size_t len, zk_mle** out) {
+    if (!is_pow2(len)) return ZK_E_NOT_POW2; // evaluation_form.rs:23-27
+    zk_mle* m = new (std::nothrow) zk_mle{c, nullptr, len, true};
+    if (!m) return ZK_E_ALLOC;
+    hipError_t e = hipMalloc(&m->d, len * kElem);
+    if (e != hipSuccess) {
+        c->err = std::string("hipMalloc table: ") + hipGetErrorString(e);
+        delete m;
+        return ZK_E_ALLOC;
+    }
+    *out = m;
+    return ZK_OK;
+}
+
+// to_bytes of a table fed to `sink` in chunks (device converts, host receives LE32 bytes)
+template <class Sink>
+int stream_le32(zk_ctx* c, const void* table, size_t len, Sink&& sink) {
+    int rc = ensure_stage(c);
+    if (rc) return rc;
+    std::vector<uint8_t> host(std::min(len, kChunkElems) * kElem);
+    for (size_t off = 0; off < len; off += kChunkElems) {
+        size_t n = std::min(kChunkElems, len - off);
+        zkk::launch_to_le32((const uint8_t*)table + off * kElem, c->stage, n, c->stream);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipMemcpyAsync(host.data(), c->stage, n * kElem, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        sink(host.data(), n * kElem, off);
+    }
+    return ZK_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+const char* zk_strerror(int s) {
+    switch (s) {
+        case ZK_OK: return "ok";
+        case ZK_E_NOT_POW2: return "Invalid Multilinear Polynomial: evaluation points length is not a power of two";
+        case ZK_E_POINTS_LEN: return "points length does not match number of variables";
+        case ZK_E_LEN_MISMATCH: return "All polynomials must have the same length";
+        case ZK_E_LAYER_OOB: return "layer index out of bounds";
+        case ZK_E_DEGREE: return "sum polynomial must be 2 product terms of 2 factors";
+        case ZK_E_ALLOC: return "allocation failed";
+        case ZK_E_HIP: return "HIP runtime error";
+        case ZK_E_ARG: return "bad argument";
+        case ZK_E_NO_DEVICE: return "no gfx950 device available (this library has no CPU path)";
+        case ZK_E_COMM: return "collective communication error";
+        default: return "unknown status";
+    }
+}
+const char* zk_last_error(const zk_ctx* ctx) { return ctx ? ctx->err.c_str() : ""; }
+const char* zk_version(void) { return "zkmi 0.1 (gfx950)"; }
+
+// ---- context --------------------------------------------------------------------------------
+int zk_ctx_create(int device_id, zk_ctx** out) {
+    if (!out) return ZK_E_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device_id < 0 || device_id >= ndev) return ZK_E_NO_DEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) return ZK_E_NO_DEVICE;
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0) return ZK_E_NO_DEVICE; // kernels are gfx950-only
+    zk_ctx* c = new (std::nothrow) zk_ctx();
+    if (!c) return ZK_E_ALLOC;
+    c->device = device_id;
+    int rc = ZK_OK;
+    auto fail = [&](hipError_t e, const char* what) {
+        if (e == hipSuccess) return false;
+        fprintf(stderr, "zkmi: %s: %s\n", what, hipGetErrorString(e));
+        rc = ZK_E_HIP;
+        return true;
+    };
+    if (fail(hipSetDevice(device_id), "hipSetDevice") ||
+        fail(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking), "hipStreamCreate") ||
+        fail(hipMalloc(&c->partials, (size_t)zkk::kMaxBlocks * 3 * kElem), "hipMalloc partials") ||
+        fail(hipMalloc(&c->sums_dev, 3 * kElem), "hipMalloc sums") ||
+        fail(hipHostMalloc((void**)&c->sums_host, 3 * kElem, hipHostMallocDefault), "hipHostMalloc sums")) {
+        zk_ctx_destroy(c);
+        return rc;
+    }
+    *out = c;
+    return ZK_OK;
+}
+
+void zk_ctx_destroy(zk_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto& s : c->prof_pending) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
+    for (auto& p : c->prof_free) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+    if (c->partials) (void)hipFree(c->partials);
+    if (c->sums_dev) (void)hipFree(c->sums_dev);
+    if (c->sums_host) (void)hipHostFree(c->sums_host);
+    if (c->work[0]) (void)hipFree(c->work[0]);
+    if (c->work[1]) (void)hipFree(c->work[1]);
+    if (c->stage) (void)hipFree(c->stage);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+void* zk_ctx_stream(zk_ctx* c) { return c ? (void*)c->stream : nullptr; }
+int zk_ctx_synchronize(zk_ctx* c) {
+    if (!c) return ZK_E_ARG;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return ZK_OK;
+}
+
+// ---- transcript -----------------------------------------------------------------------------
+zk_transcript* zk_transcript_new(void) { return new (std::nothrow) zk_transcript(); }
+zk_transcript* zk_transcript_clone(const zk_transcript* t) { return t ? new (std::nothrow) zk_transcript(*t) : nullptr; }
+void zk_transcript_free(zk_transcript* t) { delete t; }
+int zk_transcript_append(zk_transcript* t, const uint8_t* data, size_t len) {
+    if (!t || (!data && len)) return ZK_E_ARG;
+    if (len) t->append(data, len);
+    return ZK_OK;
+}
+int zk_transcript_sample_challenge(zk_transcript* t, uint64_t out[4]) {
+    if (!t || !out) return ZK_E_ARG;
+    zkh::store(out, t->sample());
+    return ZK_OK;
+}
+int zk_transcript_sample_n_challenges(zk_transcript* t, size_t n, uint64_t* out) {
+    if (!t || (!out && n)) return ZK_E_ARG;
+    for (size_t i = 0; i < n; ++i) zkh::store(out + 4 * i, t->sample());
+    return ZK_OK;
+}
+int zk_transcript_peek_digest(const zk_transcript* t, uint8_t out[32]) {
+    if (!t || !out) return ZK_E_ARG;
+    t->hasher.peek(out);
+    return ZK_OK;
+}
+
+// ---- MLE --------------------------------------------------------------------------------------
+int zk_mle_upload_mont(zk_ctx* c, const uint64_t* limbs, size_t len, zk_mle** out) {
+    if (!c || !limbs || !out) return ZK_E_ARG;
+    int rc = set_device(c);
+    if (rc) return rc;
+    zk_mle* m = nullptr;
+    if ((rc = new_mle(c, len, &m))) return rc;
+    hipError_t e = hipMemcpyAsync(m->d, limbs, len * kElem, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) {
+        c->err = std::string("upload: ") + hipGetErrorString(e);
+        zk_mle_free(m);
+        return ZK_E_HIP;
+    }
+    *out = m;
+    return ZK_OK;
+}
+
+int zk_mle_upload_le32(zk_ctx* c, const uint8_t* bytes, size_t len, zk_mle** out) {
+    if (!c || !bytes || !out) return ZK_E_ARG;
+    int rc = set_device(c);
+    if (rc) return rc;
+    zk_mle* m = nullptr;
+    if ((rc = new_mle(c, len, &m))) return rc;
+    if ((rc = ensure_stage(c))) { zk_mle_free(m); return rc; }
+    for (size_t off = 0; off < len; off += kChunkElems) {
+        size_t n = std::min(kChunkElems, len - off);
+        hipError_t e = hipMemcpyAsync(c->stage, bytes + off * kElem, n * kElem, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) {
+            zkk::launch_from_le32(c->stage, (uint8_t*)m->d + off * kElem, n, c->stream);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) {
+            c->err = std::string("upload_le32: ") + hipGetErrorString(e);
+            zk_mle_free(m);
+            return ZK_E_HIP;
+        }
+    }
+    *out = m;
+    return ZK_OK;
+}
+
+int zk_mle_wrap_device(zk_ctx* c, void* dptr, size_t len, zk_mle** out) {
+    if (!c || !dptr || !out) return ZK_E_ARG;
+    if (!is_pow2(len)) return ZK_E_NOT_POW2;
+    if ((uintptr_t)dptr % 16) return ZK_E_ARG; // 16-byte vector loads
+    zk_mle* m = new (std::nothrow) zk_mle{c, dptr, len, false};
+    if (!m) return ZK_E_ALLOC;
+    *out = m;
+    return ZK_OK;
+}
+
+int zk_mle_generate(zk_ctx* c, uint64_t seed, uint64_t first, size_t len, zk_mle** out) {
+    if (!c || !out) return ZK_E_ARG;
+    int rc = set_device(c);
+    if (rc) return rc;
+    zk_mle* m = nullptr;
+    if ((rc = new_mle(c, len, &m))) return rc;
+    zkk::launch_generate(m->d, seed, first, len, c->stream);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) {
+        c->err = std::string("generate: ") + hipGetErrorString(e);
+        zk_mle_free(m);
+        return ZK_E_HIP;
+    }
+    *out = m;
+    return ZK_OK;
+}
+
+int zk_mle_clone(const zk_mle* src, zk_mle** out) {
+    if (!src || !out) return ZK_E_ARG;
+    zk_ctx* c = src->ctx;
+    int rc = set_device(c);
+    if (rc) return rc;
+    zk_mle* m = nullptr;
+    if ((rc = new_mle(c, src->len, &m))) return rc;
+    hipError_t e = hipMemcpyAsync(m->d, src->d, src->len * kElem, hipMemcpyDeviceToDevice, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) {
+        c->err = std::string("clone: ") + hipGetErrorString(e);
+        zk_mle_free(m);
+        return ZK_E_HIP;
+    }
+    *out = m;
+    return ZK_OK;
+}
+
+void zk_mle_free(zk_mle* m) {
+    if (!m) return;
+    if (m->owned && m->d) {
+        (void)hipSetDevice(m->ctx->device);
+        (void)hipFree(m->d);
+    }
+    delete m;
+}
+size_t zk_mle_len(const zk_mle* m) { return m ? m->len : 0; }
+void* zk_mle_device_ptr(const zk_mle* m) { return m ? m->d : nullptr; }
+
+int zk_mle_download_mont(const zk_mle* m, uint64_t* out) {
+    if (!m || !out) return ZK_E_ARG;
+    zk_ctx* c = m->ctx;
+    int rc = set_device(c);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(out, m->d, m->len * kElem, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return ZK_OK;
+}
+
+int zk_mle_to_le32(const zk_mle* m, uint8_t* out) {
+    if (!m || !out) return ZK_E_ARG;
+    zk_ctx* c = m->ctx;
+    int rc = set_device(c);
+    if (rc) return rc;
+    return stream_le32(c, m->d, m->len, [&](const uint8_t* p, size_t nbytes, size_t off) { std::memcpy(out + off * kElem, p, nbytes); });
+}
+
+int zk_mle_partially_evaluate(const zk_mle* m, size_t var, const uint64_t r[4], zk_mle** out) {
+    if (!m || !r || !out) return ZK_E_ARG;
+    zk_ctx* c = m->ctx;
+    unsigned nv = ilog2(m->len);
+    if (var >= nv) return ZK_E_POINTS_LEN; // Rust: `number_of_variables() - 1 - idx` underflows and panics
+    int rc = set_device(c);
+    if (rc) return rc;
+    zk_mle* o = nullptr;
+    if ((rc = new_mle(c, m->len / 2, &o))) return rc;
+    {
+        ProfScope ps(c, ZK_K_FOLD, (uint64_t)m->len * 48);
+        zkk::launch_fold_var(m->d, o->d, m->len / 2, (int)(nv - 1 - var), r, c->stream);
+    }
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) {
+        c->err = std::string("partially_evaluate: ") + hipGetErrorString(e);
+        zk_mle_free(o);
+        return ZK_E_HIP;
+    }
+    prof_collect(c);
+    *out = o;
+    return ZK_OK;
+}
+
+int zk_mle_evaluate(const zk_mle* m, const uint8_t* has, const uint64_t* vals, size_t npts, zk_mle** out) {
+    if (!m || !out || (npts && (!has || !vals))) return ZK_E_ARG;
+    if (npts != ilog2(m->len)) return ZK_E_POINTS_LEN; // evaluation_form.rs:197-199
+    zk_mle* acc = nullptr;
+    int rc = zk_mle_clone(m, &acc); // MultiLinearPolynomial::new(&self.evaluation_points), :204
+    if (rc) return rc;
+    size_t done = 0;
+    for (size_t idx = 0; idx < npts; ++idx) {
+        if (!has[idx]) continue;
+        zk_mle* next = nullptr;
+        rc = zk_mle_partially_evaluate(acc, idx - done, vals + 4 * idx, &next); // :208
+        zk_mle_free(acc);
+        if (rc) return rc;
+        acc = next;
+        ++done;
+    }
+    *out = acc;
+    return ZK_OK;
+}
+
+int zk_mle_evaluation_sum(const zk_mle* m, uint64_t out[4]) {
+    if (!m || !out) return ZK_E_ARG;
+    zk_ctx* c = m->ctx;
+    int rc = set_device(c);
+    if (rc) return rc;
+    int g = zkk::launch_sum_all(m->d, m->len, c->partials, c->stream);
+    HIPCHK(c, hipGetLastError());
+    Fq s;
+    if ((rc = fetch_sums(c, g, 1, &s))) return rc;
+    zkh::store(out, s);
+    return ZK_OK;
+}
+
+int zk_mle_round_sums(const zk_mle* m, uint64_t out[8]) {
+    if (!m || !out) return ZK_E_ARG;
+    if (m->len < 2) return ZK_E_POINTS_LEN;
+    zk_ctx* c = m->ctx;
+    int rc = set_device(c);
+    if (rc) return rc;
+    int g;
+    {
+        ProfScope ps(c, ZK_K_ROUND_SUMS, (uint64_t)m->len * 32);
+        g = zkk::launch_round_sums(m->d, m->len / 2, c->partials, c->stream);
+    }
+    HIPCHK(c, hipGetLastError());
+    Fq e[2];
+    if ((rc = fetch_sums(c, g, 2, e))) return rc;
+    prof_collect(c);
+    zkh::store(out, e[0]);
+    zkh::store(out + 4, e[1]);
+    return ZK_OK;
+}
+
+// ---- sumcheck prover: single MLE ---------------------------------------------------------------
+int zk_sumcheck_prove_mle(zk_ctx* c, const zk_mle* poly, int absorb_table, zk_transcript* transcript,
+                          uint64_t claim_out[4], uint64_t* coeffs_out, uint64_t* challenges_out) {
+    if (!c || !poly || !claim_out) return ZK_E_ARG;
+    if (poly->ctx != c) return ZK_E_ARG;
+    const size_t len = poly->len;
+    const unsigned n = ilog2(len);
+    if (n && !coeffs_out) return ZK_E_ARG;
+    int rc = set_device(c);
+    if (rc) return rc;
+
+    zk_transcript local;
+    zk_transcript* tr = transcript ? transcript : &local; // Transcript::new(), prover.rs:159
+    if (!transcript || absorb_table) {                      // transcript.append(&init_polynomial.to_bytes()), :162
+        rc = stream_le32(c, poly->d, len, [&](const uint8_t* p, size_t nbytes, size_t) { tr->append(p, nbytes); });
+        if (rc) return rc;
+    }
+
+    Fq e[2];
+    if (n == 0) { // zero variables: no rounds; initial_claim_sum = the single entry
+        HIPCHK(c, hipMemcpyAsync(c->sums_host, poly->d, kElem, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        std::memcpy(claim_out, c->sums_host, kElem);
+        return ZK_OK;
+    }
+    if (n >= 2) {
+        if ((rc = ensure_work(c, 0, len / 2 * kElem))) return rc;
+        if (n >= 3 && (rc = ensure_work(c, 1, len / 4 * kElem))) return rc;
+    }
+
+    int g;
+    {
+        ProfScope ps(c, ZK_K_ROUND_SUMS, (uint64_t)len * 32);
+        g = zkk::launch_round_sums(poly->d, len / 2, c->partials, c->stream);
+    }
+    HIPCHK(c, hipGetLastError());
+    if ((rc = fetch_sums(c, g, 2, e))) return rc;
+    zkh::store(claim_out, zkh::add(e[0], e[1])); // evaluation_sum(), prover.rs:170
+
+    const void* cur = poly->d;
+    size_t curlen = len;
+    for (unsigned k = 0; k < n; ++k) {
+        Fq claimed = zkh::add(e[0], e[1]);  // prover.rs:118
+        Fq c1 = zkh::sub(e[1], e[0]);       // interpolate([0,1],[e0,e1]) = [e0, e1-e0], :120-123
+        tr->append_fq(claimed);             // :126-129
+        tr->append_fq(e[0]);
+        tr->append_fq(c1);
+        Fq r = tr->sample();                // :141-144
+        zkh::store(coeffs_out + 8 * k, e[0]);
+        zkh::store(coeffs_out + 8 * k + 4, c1);
+        if (challenges_out) zkh::store(challenges_out + 4 * k, r);
+        if (k + 1 == n) break; // the last fold's output (one entry) is never used by the prover
+        void* dst = c->work[k & 1];
+        {
+            ProfScope ps(c, ZK_K_FOLD_SUMS, (uint64_t)curlen * 48);
+            g = zkk::launch_fold_sums(cur, dst, curlen / 4, r.l, c->partials, c->stream);
+        }
+        HIPCHK(c, hipGetLastError());
+        if ((rc = fetch_sums(c, g, 2, e))) return rc;
+        cur = dst;
+        curlen /= 2;
+    }
+    prof_collect(c);
+    return ZK_OK;
+}
+
+// ---- sumcheck prover: Sum[Prod[t0,t1], Prod[t2,t3]] ---------------------------------------------
+int zk_sumcheck_prove_sum2x2(zk_ctx* c, zk_mle* const tables[4], const uint64_t claim[4], zk_transcript* tr,
+                             uint64_t* coeffs_out, uint64_t* challenges_out) {
+    if (!c || !tables || !claim || !tr) return ZK_E_ARG;
+    for (int k = 0; k < 4; ++k)
+        if (!tables[k] || tables[k]->ctx != c) return ZK_E_ARG;
+    const size_t len = tables[0]->len;
+    for (int k = 1; k < 4; ++k)
+        if (tables[k]->len != len) return ZK_E_LEN_MISMATCH; // product_polynomial.rs:15-19, sum_polynomial.rs:15-19
+    const unsigned n = ilog2(len);
+    if (n == 0) return ZK_OK; // zero variables: no rounds, nothing appended
+    if (!coeffs_out) return ZK_E_ARG;
+    int rc = set_device(c);
+    if (rc) return rc;
+    // ping-pong scratch: 4 tables of len/2 in work[0], 4 of len/4 in work[1]
+    if (n >= 2 && (rc = ensure_work(c, 0, 4 * (len / 2) * kElem))) return rc;
+    if (n >= 3 && (rc = ensure_work(c, 1, 4 * (len / 4) * kElem))) return rc;
+
+    const void* cur[4];
+    for (int k = 0; k < 4; ++k) cur[k] = tables[k]->d;
+    size_t curlen = len;
+    Fq ev[3];
+    int g;
+    {
+        ProfScope ps(c, ZK_K_EVAL3, (uint64_t)len * 32 * 4);
+        g = zkk::launch_eval3(cur, len / 2, c->partials, c->stream);
+    }
+    HIPCHK(c, hipGetLastError());
+    if ((rc = fetch_sums(c, g, 3, ev))) return rc;
+
+    const Fq inv2 = zkh::inv2();
+    for (unsigned k = 0; k < n; ++k) {
+        // interpolate([0,1,2], ev) in closed form (dense_coefficient_form.rs:52-88 gives the same
+        // canonical coefficients): c0 = ev0, c2 = (ev0 - 2 ev1 + ev2)/2, c1 = ev1 - ev0 - c2
+        Fq claimed = zkh::add(ev[0], ev[1]); // prover.rs:102
+        Fq c2 = zkh::mul(zkh::add(zkh::sub(ev[0], zkh::add(ev[1], ev[1])), ev[2]), inv2);
+        Fq c1 = zkh::sub(zkh::sub(ev[1], ev[0]), c2);
+        tr->append_fq(claimed); // :126-129
+        tr->append_fq(ev[0]);
+        tr->append_fq(c1);
+        tr->append_fq(c2);
+        Fq r = tr->sample(); // :132-135
+        zkh::store(coeffs_out + 12 * k, ev[0]);
+        zkh::store(coeffs_out + 12 * k + 4, c1);
+        zkh::store(coeffs_out + 12 * k + 8, c2);
+        if (challenges_out) zkh::store(challenges_out + 4 * k, r);
+        if (k + 1 == n) break;
+        void* dst[4];
+        const size_t outlen = curlen / 2;
+        for (int t = 0; t < 4; ++t) dst[t] = (uint8_t*)c->work[k & 1] + (size_t)t * outlen * kElem;
+        {
+            ProfScope ps(c, ZK_K_FOLD4_EVAL3, (uint64_t)curlen * 48 * 4);
+            g = zkk::launch_fold4_eval3(cur, dst, curlen / 4, r.l, c->partials, c->stream);
+        }
+        HIPCHK(c, hipGetLastError());
+        if ((rc = fetch_sums(c, g, 3, ev))) return rc;
+        for (int t = 0; t < 4; ++t) cur[t] = dst[t];
+        curlen = outlen;
+    }
+    prof_collect(c);
+    return ZK_OK;
+}
+
+// ---- verifier ------------------------------------------------------------------------------------
+int zk_sumcheck_partial_verify(const uint64_t claim[4], const uint64_t* coeffs, size_t n_rounds, size_t ncoef,
+                               zk_transcript* tr, int* ok_out, uint64_t final_claim_out[4], uint64_t* challenges_out) {
+    if (!claim || !tr || !ok_out || (n_rounds && !coeffs) || ncoef == 0 || ncoef > 16) return ZK_E_ARG;
+    Fq cur = zkh::load(claim); // verifier.rs:34
+    int ok = 1;
+    const Fq one = zkh::one();
+    for (size_t k = 0; k < n_rounds; ++k) {
+        Fq g[16];
+        for (size_t i = 0; i < ncoef; ++i) g[i] = zkh::load(coeffs + 4 * (k * ncoef + i));
+        Fq s = zkh::add(zkh::poly_eval(g, ncoef, zkh::zero()), zkh::poly_eval(g, ncoef, one)); // g(0)+g(1), :41
+        if (s != cur) { ok = 0; break; }
+        tr->append_fq(cur); // :47-50
+        for (size_t i = 0; i < ncoef; ++i) tr->append_fq(g[i]);
+        Fq r = tr->sample(); // :52
+        if (challenges_out) zkh::store(challenges_out + 4 * k, r);
+        cur = zkh::poly_eval(g, ncoef, r); // :58
+    }
+    *ok_out = ok;
+    if (final_claim_out) zkh::store(final_claim_out, cur);
+    return ZK_OK;
+}
+
+int zk_sumcheck_verify_mle(zk_ctx* c, const zk_mle* poly, const uint64_t claim[4], const uint64_t* coeffs, size_t n_rounds,
+                           int* ok_out) {
+    if (!c || !poly || !claim || !ok_out || poly->ctx != c) return ZK_E_ARG;
+    *ok_out = 0;
+    int rc = set_device(c);
+    if (rc) return rc;
+    zk_transcript tr;
+    rc = stream_le32(c, poly->d, poly->len, [&](const uint8_t* p, size_t nbytes, size_t) { tr.append(p, nbytes); }); // verifier.rs:71
+    if (rc) return rc;
+    uint64_t s[4];
+    if ((rc = zk_mle_evaluation_sum(poly, s))) return rc;
+    if (zkh::load(s) != zkh::load(claim)) return ZK_OK; // :74-76
+    std::vector<uint64_t> ch(4 * (n_rounds ? n_rounds : 1));
+    uint64_t final_claim[4];
+    int ok = 0;
+    if ((rc = zk_sumcheck_partial_verify(claim, coeffs, n_rounds, 2, &tr, &ok, final_claim, ch.data()))) return rc;
+    if (!ok || n_rounds == 0) return ZK_OK; // :81-91
+    // perform_oracle_check :15-26
+    if (n_rounds != ilog2(poly->len)) return ZK_E_POINTS_LEN; // evaluate() panics on a length mismatch
+    std::vector<uint8_t> has(n_rounds, 1);
+    zk_mle* e = nullptr;
+    if ((rc = zk_mle_evaluate(poly, has.data(), ch.data(), n_rounds, &e))) return rc;
+    uint64_t v[4];
+    rc = zk_mle_download_mont(e, v);
+    zk_mle_free(e);
+    if (rc) return rc;
+    *ok_out = zkh::load(v) == zkh::load(final_claim);
+    return ZK_OK;
+}
+
+// ---- measurement ----------------------------------------------------------------------------------
+int zk_prof_enable(zk_ctx* c, int on) {
+    if (!c) return ZK_E_ARG;
+    c->prof_on = on != 0;
+    return ZK_OK;
+}
+int zk_prof_reset(zk_ctx* c) {
+    if (!c) return ZK_E_ARG;
+    for (int k = 0; k < ZK_K_COUNT; ++k) { c->prof_launches[k] = 0; c->prof_ms[k] = 0; c->prof_bytes[k] = 0; }
+    return ZK_OK;
+}
+int zk_prof_read(zk_ctx* c, int kernel, uint64_t* launches, double* ms, uint64_t* bytes) {
+    if (!c || kernel < 0 || kernel >= ZK_K_COUNT) return ZK_E_ARG;
+    if (launches) *launches = c->prof_launches[kernel];
+    if (ms) *ms = c->prof_ms[kernel];
+    if (bytes) *bytes = c->prof_bytes[kernel];
+    return ZK_OK;
+}
+int zk_bench_modmul(zk_ctx* c, int blocks, int iters, double* ms_out) {
+    if (!c || blocks <= 0 || iters <= 0 || !ms_out) return ZK_E_ARG;
+    int rc = set_device(c);
+    if (rc) return rc;
+    void* buf = nullptr;
+    HIPCHK(c, hipMalloc(&buf, (size_t)blocks * 256 * kElem));
+    zkk::launch_generate(buf, 42, 0, (size_t)blocks * 256, c->stream);
+    hipEvent_t a, b;
+    HIPCHK(c, hipEventCreate(&a));
+    HIPCHK(c, hipEventCreate(&b));
+    zkk::launch_modmul_probe(buf, blocks, 4, c->stream); // warm-up
+    HIPCHK(c, hipEventRecord(a, c->stream));
+    zkk::launch_modmul_probe(buf, blocks, iters, c->stream);
+    HIPCHK(c, hipEventRecord(b, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    float ms = 0;
+    HIPCHK(c, hipEventElapsedTime(&ms, a, b));
+    *ms_out = ms;
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    HIPCHK(c, hipFree(buf));
+    return ZK_OK;
+}
+
+} // extern "C"
