@@ -36,6 +36,8 @@ def parse():
     ap.add_argument("--no-absorb", action="store_true", help="skip the one-off 32*N-byte Keccak table absorb")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-log-n", type=int, default=24, help="bounded CPU sample size (2^k entries)")
+    ap.add_argument("--fold-batch", type=int, default=0, help="rounds bound per device pass (0 = library default)")
+    ap.add_argument("--fold-variant", type=int, default=0, help="0 eq-weight inner product, 1 tree, 2 tree+double buffer")
     return ap.parse_args()
 
 
@@ -101,6 +103,8 @@ def main():
             dist.barrier()
 
     ctx = zk_amd.Context(local_rank)
+    if args.fold_batch:
+        ctx.set_fold_batch(args.fold_batch, args.fold_variant)
     n = 1 << args.log_n
 
     if world > 1:
@@ -165,7 +169,7 @@ def bench_single(args, ctx, zk_amd, np):
         def step():
             return zk_amd.SumcheckProver.generate_round_polys(poly, base.clone())
 
-        kernel, workload = "fold_sums", f"single-MLE sumcheck, 2^{args.log_n} entries, 1 GPU"
+        kernel, workload = "multifold", f"single-MLE sumcheck, 2^{args.log_n} entries, 1 GPU"
     else:
         tabs = [zk_amd.MultiLinearPolynomial.generate(SEED + k, n, ctx=ctx) for k in range(4)]
         f = zk_amd.SumPolynomial([zk_amd.ProductPolynomial(tabs[:2]), zk_amd.ProductPolynomial(tabs[2:])])
@@ -196,7 +200,7 @@ def bench_single(args, ctx, zk_amd, np):
     ms_per_step = dt * 1e3 / args.steps
 
     kernels = {}
-    for name in ("round_sums", "fold_sums", "eval3", "fold4_eval3"):
+    for name in ("block_sums", "multifold", "eval3", "fold4_eval3"):
         p = ctx.prof_read(name)
         if p["launches"]:
             kernels[name] = {
@@ -209,7 +213,8 @@ def bench_single(args, ctx, zk_amd, np):
         "bound": "hbm", "kernel": kernel, "achieved": dom["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": dom["achieved_GBs"] / HBM_PEAK_GBS, "traffic": None,
         "note": "achieved = algorithmic bytes of all launches of the kernel in the timed steps / their summed "
-                "HIP-event durations (48 B per input entry per table; launch sizes halve every round)",
+                "HIP-event durations (multifold: 32 B per input entry read + 32 B per output entry written; "
+                "fold4_eval3: 48 B per input entry per table)",
     }
     # int32-ALU side: Montgomery multiplies per second from the in-register probe
     blocks, iters = 2048, 2000

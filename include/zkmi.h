@@ -56,7 +56,7 @@ const char *zk_version(void);
 
 /* ---- context ------------------------------------------------------------------------- */
 int zk_ctx_create(int device_id, zk_ctx **out);
-void zk_ctx_destroy(zk_ctx *ctx);
+void zk_ctx_destroy(zk_ctx *ctx); /* tables of this context may be freed afterwards, not used */
 /* the HIP stream (hipStream_t) every kernel of this context is launched on */
 void *zk_ctx_stream(zk_ctx *ctx);
 int zk_ctx_synchronize(zk_ctx *ctx);
@@ -120,13 +120,19 @@ int zk_sumcheck_partial_verify(const uint64_t claim_mont[4], const uint64_t *coe
 int zk_sumcheck_verify_mle(zk_ctx *ctx, const zk_mle *poly, const uint64_t claim_mont[4], const uint64_t *coeffs,
                            size_t n_rounds, int *ok_out);
 
-/* ---- measurement hooks (no reference counterpart) ------------------------------------- */
-enum { ZK_K_ROUND_SUMS = 0, ZK_K_FOLD_SUMS = 1, ZK_K_FOLD = 2, ZK_K_EVAL3 = 3, ZK_K_FOLD4_EVAL3 = 4, ZK_K_COUNT = 8 };
+/* ---- tuning / measurement hooks (no reference counterpart) ---------------------------- */
+/* Rounds bound per device pass by the single-MLE prover (1..4, default 3) and the fold kernel
+ * variant: 0 = inner product with eq weights, one reduction per output (default); 1 = fold tree;
+ * 2 = fold tree with register double-buffering; 3 = as 0 with 2-element load groups.  Proof bytes do not
+ * depend on either. */
+int zk_ctx_set_fold_batch(zk_ctx *ctx, int rounds_per_pass, int variant);
+enum { ZK_K_BLOCK_SUMS = 0, ZK_K_MULTIFOLD = 1, ZK_K_FOLD = 2, ZK_K_EVAL3 = 3, ZK_K_FOLD4_EVAL3 = 4, ZK_K_COUNT = 8 };
 /* per-kernel HIP-event timing of the launches made by the provers on this context */
 int zk_prof_enable(zk_ctx *ctx, int on);
 int zk_prof_reset(zk_ctx *ctx);
 /* totals since the last reset: launches, elapsed ms (HIP events on the context stream) and
- * ALGORITHMIC bytes (fold 48 B/input entry, round sums 32 B/entry, ...) */
+ * ALGORITHMIC bytes (block sums 32 B/entry; m-round fold 32 B per input entry + 32 B per
+ * output entry; degree-2 kernels 32 B (eval) / 48 B (fold+eval) per input entry per table) */
 int zk_prof_read(zk_ctx *ctx, int kernel, uint64_t *launches, double *ms, uint64_t *alg_bytes);
 /* Montgomery-multiply throughput probe: `iters` dependent multiplies per lane on `blocks` x 256
  * lanes; returns elapsed ms.  Used for the int32-ALU roofline figure. */

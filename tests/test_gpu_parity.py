@@ -156,6 +156,23 @@ def test_sumcheck_vs_oracle_random_full_range(ctx, log_n):
     assert ok == O.sumcheck_verify(table, oclaim, ocoeffs)
 
 
+@pytest.mark.parametrize("batch,db", [(1, 0), (1, 1), (1, 2), (2, 0), (2, 1), (2, 2), (2, 3), (3, 0), (3, 1), (3, 2), (3, 3), (4, 0), (4, 1), (4, 3)])
+def test_sumcheck_every_fold_batch_setting_gives_the_same_proof(batch, db):
+    """Rounds-per-pass batching is an execution schedule, not a protocol change: proofs are identical."""
+    c = zk_amd.Context(0)
+    c.set_fold_batch(batch, db)
+    for log_n in (1, 2, 3, 4, 5, 6, 7, 9, 13, 17):
+        table = O.gen_table(SEED + 60 + log_n, 0, 1 << log_n)
+        poly = MLE(table, ctx=c)
+        proof, ch = zk_amd.SumcheckProver.generate_sumcheck_proof(poly, return_challenges=True)
+        oclaim, ocoeffs, och = O.sumcheck_prove(table)
+        assert list(proof.initial_claim_sum) == list(oclaim), (batch, db, log_n)
+        assert np.array_equal(proof.round_polys, ocoeffs), (batch, db, log_n)
+        assert np.array_equal(ch, och), (batch, db, log_n)
+    with pytest.raises(zk_amd.ZkError):
+        c.set_fold_batch(5, 0)
+
+
 def test_sumcheck_reference_fail_vector_and_tampering(ctx):
     # sumcheck_protocol.rs:52-82: the hand-forged proof is rejected
     bad_table = MLE(O.ints_to_mont([0, 0, 0, 3, 0, 0, 2, 65]))

@@ -24,11 +24,19 @@ T01, T0, T1, T2 = "v[2:3]", "v2", "v3", "v4"
 SP = [f"s{40 + i}" for i in range(8)]
 SN = "s48"
 VCLOB = ["v2", "v3", "v4"]
-SCLOB = [f"s{40 + i}" for i in range(9)]
+CARRY = ["s[50:51]", "s[52:53]", "s[54:55]"]
+SCLOB = [f"s{40 + i}" for i in range(9)] + [f"s{50 + i}" for i in range(6)]
 
 
 def emit(variant):
-    """variant 'vv': b in VGPRs; 'vs': b in SGPRs (wave-uniform multiplier, e.g. the challenge)."""
+    """variant 'vv': b in VGPRs; 'vs': b in SGPRs (wave-uniform multiplier, e.g. the challenge).
+
+    Hazard rule honoured here (hipcc does not pad inside an asm string): on gfx940/gfx950 a VALU
+    instruction that READS an SGPR/VCC written by a VALU instruction needs 2 wait states in between
+    (LLVM's VALUWriteSGPRVALURead; hipcc itself emits `s_nop 1` between chained v_addc_co).  The
+    v_mad_u64_u32 carry-outs therefore go to a ring of three SGPR pairs and each v_addc_co that
+    consumes one is issued two instructions later, behind the next products -- no padding needed
+    except at column ends and in the final subtract chain."""
     L = []
     A = lambda i: f"%[a{i}]"
     B = lambda i: f"%[b{i}]"
@@ -38,11 +46,30 @@ def emit(variant):
     L.append(f"s_mov_b32 {SN}, 0x{NINV:08x}")
     L += [f"v_mov_b32 {T0}, 0", f"v_mov_b32 {T1}, 0", f"v_mov_b32 {T2}, 0"]
 
+    pending = []  # (carry pair, index in L of the producing mad)
+    nmad = [0]
+
+    def addc_oldest():
+        pair, at = pending.pop(0)
+        gap = len(L) - at - 1  # instructions issued since the mad
+        if gap < 2:
+            L.append(f"s_nop {1 - gap}")  # s_nop N = N+1 wait states
+        L.append(f"v_addc_co_u32_e64 {T2}, vcc, 0, {T2}, {pair}")
+
     def mac(x, y):
-        L.append(f"v_mad_u64_u32 {T01}, vcc, {x}, {y}, {T01}")
-        L.append(f"v_addc_co_u32 {T2}, vcc, 0, {T2}, vcc")
+        pair = CARRY[nmad[0] % 3]
+        nmad[0] += 1
+        L.append(f"v_mad_u64_u32 {T01}, {pair}, {x}, {y}, {T01}")
+        pending.append((pair, len(L) - 1))
+        if len(pending) == 3:
+            addc_oldest()
+
+    def flush():
+        while pending:
+            addc_oldest()
 
     def shift():
+        flush()
         L.append(f"v_mov_b32 {T0}, {T1}")
         L.append(f"v_mov_b32 {T1}, {T2}")
         L.append(f"v_mov_b32 {T2}, 0")
@@ -60,18 +87,22 @@ def emit(variant):
             mac(A(i), B(k - i))
         for i in range(k - 7, 8):
             mac(M(i), SP[k - i])
-        # m_{k-8} was last used in column k-1 (i = k-8 pairs with p_8: none), so its register is free
+        # m_{k-8} was last used in column k-1, so its register is free to take result limb k-8
         L.append(f"v_mov_b32 {M(k - 8)}, {T0}")
         if k < 15:
             shift()
+    flush()
     # conditional subtraction: a_j <- r_j - p_j (a is dead), select on the final borrow.
     # v_subb reads vcc, so the modulus limb cannot also come from an SGPR (one constant-bus
-    # read per VALU op on gfx9): stage p_j through a_j first.
+    # read per VALU op on gfx9): stage p_j through a_j first.  Each v_subb reads the vcc the
+    # previous one wrote: 2 wait states apiece.
     for j in range(8):
         L.append(f"v_mov_b32 {A(j)}, {SP[j]}")
     L.append(f"v_sub_co_u32 {A(0)}, vcc, {M(0)}, {A(0)}")
     for j in range(1, 8):
+        L.append("s_nop 1")
         L.append(f"v_subb_co_u32 {A(j)}, vcc, {M(j)}, {A(j)}, vcc")
+    L.append("s_nop 1")
     for j in range(8):
         L.append(f"v_cndmask_b32 {M(j)}, {A(j)}, {M(j)}, vcc")
     body = "\n".join(f'        "{ins}\\n\\t"' for ins in L)
@@ -107,6 +138,9 @@ print(f"#define FQ_2P_LIMBS {l32(2 * P)}")
 print(f"#define FQ_4P_LIMBS {l32(4 * P)}   // 4p < 2^256 < 6p")
 print(f"#define FQ_R2_LIMBS {l32((1 << 512) % P)}   // R^2 mod p, R = 2^256")
 print(f"#define FQ_R_LIMBS {l32((1 << 256) % P)}    // Montgomery form of 1")
+# radix-2^28 view (10 limbs) used by the carry-free multi-product accumulation (fq28_* in fq_dev.hpp)
+print("#define FQ_P28_LIMBS {" + ", ".join("0x%07xu" % ((P >> (28 * i)) & 0xFFFFFFF) for i in range(10)) + "}")
+print(f"#define FQ_NINV28 0x{(-pow(P, -1, 1 << 28)) % (1 << 28):07x}u   // -p^-1 mod 2^28")
 print()
 print(emit("vv"))
 print(emit("vs"))

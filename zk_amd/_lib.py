@@ -55,6 +55,7 @@ SYMBOLS = [
     ("zk_sumcheck_prove_sum2x2", C.c_int, [_VP, C.POINTER(_VP), u64p, _VP, u64p, u64p]),
     ("zk_sumcheck_partial_verify", C.c_int, [u64p, u64p, C.c_size_t, C.c_size_t, _VP, C.POINTER(C.c_int), u64p, u64p]),
     ("zk_sumcheck_verify_mle", C.c_int, [_VP, _VP, u64p, u64p, C.c_size_t, C.POINTER(C.c_int)]),
+    ("zk_ctx_set_fold_batch", C.c_int, [_VP, C.c_int, C.c_int]),
     ("zk_prof_enable", C.c_int, [_VP, C.c_int]),
     ("zk_prof_reset", C.c_int, [_VP]),
     ("zk_prof_read", C.c_int, [_VP, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),

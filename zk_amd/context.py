@@ -5,7 +5,7 @@ import ctypes as C
 
 from ._lib import check, lib
 
-KERNELS = {"round_sums": 0, "fold_sums": 1, "fold": 2, "eval3": 3, "fold4_eval3": 4}
+KERNELS = {"block_sums": 0, "multifold": 1, "fold": 2, "eval3": 3, "fold4_eval3": 4}
 
 
 class Context:
@@ -22,6 +22,11 @@ class Context:
 
     def synchronize(self):
         check(lib().zk_ctx_synchronize(self.h), self.h)
+
+    def set_fold_batch(self, rounds_per_pass: int, variant: int = 0):
+        """Tuning knob of the single-MLE prover (proof bytes do not depend on it).
+        variant 0 = eq-weight inner product (default), 1 = fold tree, 2 = tree + double buffering."""
+        check(lib().zk_ctx_set_fold_batch(self.h, rounds_per_pass, variant))
 
     # ---- measurement hooks
     def prof_enable(self, on: bool = True):

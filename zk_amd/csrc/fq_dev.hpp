@@ -141,6 +141,74 @@ __device__ __forceinline__ fq fq_from_mont(const fq& a) {
     return fq_mul(a, one);
 }
 
+// ---- radix-2^28 carry-free accumulation ------------------------------------------------
+// A weighted sum  sum_b a_b * w_b  (the m-variable fold written as one inner product with the
+// eq weights) needs ONE Montgomery reduction, not one per product, if the 512-bit products are
+// accumulated unreduced.  With 32-bit limbs every v_mad_u64_u32 needs its carry-out caught
+// (2 VALU ops per limb product, fq_mul_asm.inc); with 10 limbs of 28 bits a limb product is
+// < 2^56, so a u64 column takes up to 2^8 of them with no carry handling at all: 1 VALU op
+// (v_mad_u64_u32 acc, a, w, acc) per limb product, written in plain C++.
+// The reduction is Montgomery in radix 2^28 over 10 limbs, i.e. it divides by 2^280: the host
+// supplies the weights as w * 2^280 / 2^256 so the result is again in R = 2^256 Montgomery form.
+#define FQ28_MASK 0x0fffffffu
+
+__device__ __forceinline__ void fq28_unpack(const fq& a, u32 (&l)[10]) {
+    l[0] = a.v[0] & FQ28_MASK;
+    l[1] = ((a.v[0] >> 28) | (a.v[1] << 4)) & FQ28_MASK;
+    l[2] = ((a.v[1] >> 24) | (a.v[2] << 8)) & FQ28_MASK;
+    l[3] = ((a.v[2] >> 20) | (a.v[3] << 12)) & FQ28_MASK;
+    l[4] = ((a.v[3] >> 16) | (a.v[4] << 16)) & FQ28_MASK;
+    l[5] = ((a.v[4] >> 12) | (a.v[5] << 20)) & FQ28_MASK;
+    l[6] = ((a.v[5] >> 8) | (a.v[6] << 24)) & FQ28_MASK;
+    l[7] = a.v[6] >> 4;
+    l[8] = a.v[7] & FQ28_MASK;
+    l[9] = a.v[7] >> 28;
+}
+
+// acc (20 u64 columns, weight 2^(28k)) += a * w ; w: 10 wave-uniform 28-bit limbs
+__device__ __forceinline__ void fq28_mac(u64 (&acc)[20], const fq& a, const u32* __restrict__ w) {
+    u32 l[10];
+    fq28_unpack(a, l);
+#pragma unroll
+    for (int j = 0; j < 10; ++j) {
+        const u32 wj = w[j];
+#pragma unroll
+        for (int i = 0; i < 10; ++i) acc[i + j] += (u64)l[i] * wj;
+    }
+}
+
+// Montgomery reduction radix 2^28: returns acc * 2^-280 mod p, fully reduced, as 8 x u32.
+// Requires acc < p * 2^280 * (1 + small): columns stay below 2^64 for up to 16 accumulated products.
+__device__ __forceinline__ fq fq28_redc(u64 (&acc)[20]) {
+    const u32 p28[10] = FQ_P28_LIMBS;
+#pragma unroll
+    for (int k = 0; k < 10; ++k) {
+        const u32 m = (((u32)acc[k] & FQ28_MASK) * FQ_NINV28) & FQ28_MASK;
+#pragma unroll
+        for (int i = 0; i < 10; ++i) acc[k + i] += (u64)m * p28[i];
+        acc[k + 1] += acc[k] >> 28; // low 28 bits of column k are now zero
+    }
+    // normalise columns 10..19 to 28-bit limbs (value < 2p < 2^255: column 19 ends up < 2^4)
+    u32 l[10];
+    u64 carry = 0;
+#pragma unroll
+    for (int k = 0; k < 10; ++k) {
+        u64 v = acc[10 + k] + carry;
+        l[k] = (u32)v & FQ28_MASK;
+        carry = v >> 28;
+    }
+    fq r;
+    r.v[0] = l[0] | (l[1] << 28);
+    r.v[1] = (l[1] >> 4) | (l[2] << 24);
+    r.v[2] = (l[2] >> 8) | (l[3] << 20);
+    r.v[3] = (l[3] >> 12) | (l[4] << 16);
+    r.v[4] = (l[4] >> 16) | (l[5] << 12);
+    r.v[5] = (l[5] >> 20) | (l[6] << 8);
+    r.v[6] = (l[6] >> 24) | (l[7] << 4);
+    r.v[7] = l[8] | (l[9] << 28);
+    return fq_reduce_once(r);
+}
+
 // ---- reductions ----------------------------------------------------------------------
 __device__ __forceinline__ fq fq_shfl_down(const fq& a, int off) {
     fq o;

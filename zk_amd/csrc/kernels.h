@@ -14,8 +14,18 @@ namespace zkk {
 // that the second stage stays a single block (cdna_hip_programming.md, Guideline 11)
 static constexpr int kMaxBlocks = 2048;
 
-int launch_round_sums(const void* T, size_t half, void* partials, hipStream_t st);
-int launch_fold_sums(const void* src, void* dst, size_t q, const uint64_t r[4], void* partials, hipStream_t st);
+static constexpr int kMaxFoldBatch = 4; // rounds bound per pass (k_multifold<M>)
+// out[b] (b < 2^log_ob) = sum of the b-th contiguous block of T (L entries); partials is scratch
+int launch_block_sums(const void* T, size_t L, int log_ob, void* partials, void* out, hipStream_t st);
+// dst (Lout entries) = src (Lout << m entries) with its top m variables bound to r[0..m) (4 limbs each);
+// out[c] (c < 2^log_ob) = sum of the c-th contiguous block of dst.  db: register double-buffering.
+int launch_multifold(int m, const void* src, void* dst, size_t Lout, const uint64_t* r, int log_ob, bool db, void* partials, void* out,
+                     hipStream_t st);
+// the same pass as one inner product with the eq weights: w28[b*10 + j] = limb j (28 bits) of
+// eq(r, b) * 2^280 mod p, b < 2^m (b's most significant bit belongs to r[0])
+// group = elements per register load buffer (2 or 4)
+int launch_multifold_lazy(int m, int group, const void* src, void* dst, size_t Lout, const uint32_t* w28, int log_ob, void* partials,
+                          void* out, hipStream_t st);
 void launch_fold_var(const void* src, void* dst, size_t n_out, int log_s, const uint64_t r[4], hipStream_t st);
 void launch_reduce_partials(const void* partials, int nblocks, int ns, void* out, hipStream_t st);
 int launch_sum_all(const void* T, size_t n, void* partials, hipStream_t st);

@@ -35,62 +35,192 @@ __device__ __forceinline__ void block_sum_store(fq (&acc)[NS], fq* __restrict__ 
     }
 }
 
-// ---- round reduction, MLE branch (sumcheck/src/prover.rs:108-116) ----------------------
-// partials[b*2+0] = sum over this block's share of T[0 .. half), [b*2+1] of T[half .. 2*half)
-__global__ void __launch_bounds__(kThreads) k_round_sums(const fq* __restrict__ T, size_t half, fq* __restrict__ partials) {
-    fq acc[2] = {fq_zero(), fq_zero()};
-    const size_t stride = (size_t)gridDim.x * kThreads;
-    for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < half; i += stride) {
-        fq lo = fq_load_stream(T + i), hi = fq_load_stream(T + half + i);
-        acc[0] = fq_add(acc[0], lo);
-        acc[1] = fq_add(acc[1], hi);
+// ---- batched rounds: block sums + multi-variable fold -----------------------------------------
+// The MLE-branch round polynomial (sumcheck/src/prover.rs:108-124) only needs the two half sums
+// of the current table, and summation commutes with folding the TOP variables: if
+//   S[b] = sum_j T[b * L/2^m + j]      (b < 2^m: the table cut into 2^m contiguous blocks)
+// then the half sums of T folded at r_0..r_{k-1} equal the half sums of the 2^m-entry table S
+// folded at the same points.  So one pass that produces S lets the host run m rounds (m Keccak
+// challenges) on 2^m numbers, and ONE pass then binds all m variables at once:
+//   T'[j] = fold_{r_{m-1}}( ... fold_{r_0}( T[b * L' + j] )_{b < 2^m} ... ),   L' = L / 2^m
+// (partially_evaluate((0, r)) applied m times, evaluation_form.rs:163-192 -- the same field values
+// in the same order; exact arithmetic makes the grouping irrelevant).  HBM traffic per batch is
+// 32*(L + L') bytes instead of 48*L*(1 + 1/2 + ...): 128*N -> 85*N (m=2) / 73*N (m=3) for a prove.
+//
+// Work split shared by both kernels: the OUTPUT (or, for k_block_sums, the input) is cut into
+// 2^log_ob contiguous blocks; workgroup w serves block w / gpb (gpb = gridDim.x >> log_ob) and
+// grid-strides inside it, so every thread carries ONE accumulator whatever the batch size.
+
+// partials[w] = this workgroup's share of the sum of block w / gpb of T (L entries)
+__global__ void __launch_bounds__(kThreads) k_block_sums(const fq* __restrict__ T, size_t L, int log_ob, fq* __restrict__ partials) {
+    const unsigned gpb = gridDim.x >> log_ob;
+    const unsigned c = blockIdx.x / gpb, wl = blockIdx.x % gpb;
+    const size_t Lb = L >> log_ob;
+    const fq* __restrict__ base = T + (size_t)c * Lb;
+    const size_t stride = (size_t)gpb * kThreads;
+    fq acc[1] = {fq_zero()};
+    size_t i = (size_t)wl * kThreads + threadIdx.x;
+    // two loads in flight per step
+    for (; i + stride < Lb; i += 2 * stride) {
+        fq a = fq_load_stream(base + i), b = fq_load_stream(base + i + stride);
+        acc[0] = fq_add(acc[0], fq_add(a, b));
     }
-    block_sum_store<2>(acc, partials);
+    if (i < Lb) acc[0] = fq_add(acc[0], fq_load_stream(base + i));
+    block_sum_store<1>(acc, partials);
 }
 
-// ---- fused fold + next round's reduction ------------------------------------------------
-// src has 4*q entries.  dst[i] = fold(src[i], src[i+2q]), dst[i+q] = fold(src[i+q], src[i+3q])
-// (partially_evaluate((0, r)), evaluation_form.rs:163-192); the halves of dst are summed on the
-// fly for the next round (prover.rs:113-116), so the folded table is never re-read.
-struct Quad { fq a0, a1, b0, b1; };
-__device__ __forceinline__ void load_quad(Quad& Q, const fq* __restrict__ src, size_t q, size_t i) {
-    Q.a0 = fq_load_stream(src + i);
-    Q.a1 = fq_load_stream(src + 2 * q + i);
-    Q.b0 = fq_load_stream(src + q + i);
-    Q.b1 = fq_load_stream(src + 3 * q + i);
+template <int M> struct Chal { fq r[M]; };
+
+template <int M>
+__device__ __forceinline__ void mf_load(fq (&in)[1 << M], const fq* __restrict__ src, size_t Lout, size_t j) {
+#pragma unroll
+    for (int b = 0; b < (1 << M); ++b) in[b] = fq_load_stream(src + (size_t)b * Lout + j);
 }
-__device__ __forceinline__ void fold_quad(const Quad& Q, fq* __restrict__ dst, size_t q, size_t i, const fq& r, fq (&acc)[2]) {
-    fq o0 = fq_fold(Q.a0, Q.a1, r);
-    fq o1 = fq_fold(Q.b0, Q.b1, r);
-    fq_store(dst + i, o0);
-    fq_store(dst + q + i, o1);
-    acc[0] = fq_add(acc[0], o0);
-    acc[1] = fq_add(acc[1], o1);
-}
-// Two register buffers (A, B) alternate so that the 8 x 16-byte loads of the NEXT grid-stride
-// step are in flight while the current step's ~800 VALU instructions run: without it every
-// step pays a full HBM round trip before it can start (measured 3.3 TB/s -> see DESIGN.md).
-__global__ void __launch_bounds__(kThreads) k_fold_sums(const fq* __restrict__ src, fq* __restrict__ dst, size_t q, fq r,
-                                                         fq* __restrict__ partials) {
-    fq acc[2] = {fq_zero(), fq_zero()};
-    const size_t stride = (size_t)gridDim.x * kThreads;
-    size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x;
-    Quad A, B;
-    if (i < q) load_quad(A, src, q, i);
-    while (i < q) {
-        size_t j = i + stride;
-        if (j < q) load_quad(B, src, q, j);
-        asm volatile("" ::: "memory"); // keep the prefetch above the arithmetic
-        fold_quad(A, dst, q, i, r, acc);
-        i = j;
-        if (i >= q) break;
-        j = i + stride;
-        if (j < q) load_quad(A, src, q, j);
-        asm volatile("" ::: "memory");
-        fold_quad(B, dst, q, i, r, acc);
-        i = j;
+// binds the top M variables: level l pairs (b, b + 2^(M-1-l)) with challenge l (variable 0 = MSB)
+template <int M>
+__device__ __forceinline__ fq mf_tree(fq (&in)[1 << M], const Chal<M>& ch) {
+#pragma unroll
+    for (int l = 0; l < M; ++l) {
+        const int half = 1 << (M - 1 - l);
+#pragma unroll
+        for (int b = 0; b < half; ++b) in[b] = fq_fold(in[b], in[b + half], ch.r[l]);
     }
-    block_sum_store<2>(acc, partials);
+    return in[0];
+}
+
+// src: Lout << M entries, dst: Lout entries.  DB: a second register buffer keeps the next step's
+// 2^M element loads in flight under the current step's arithmetic.
+template <int M, bool DB>
+__global__ void __launch_bounds__(kThreads) k_multifold(const fq* __restrict__ src, fq* __restrict__ dst, size_t Lout, Chal<M> ch,
+                                                         int log_ob, fq* __restrict__ partials) {
+    const unsigned gpb = gridDim.x >> log_ob;
+    const unsigned c = blockIdx.x / gpb, wl = blockIdx.x % gpb;
+    const size_t Lb = Lout >> log_ob;
+    const size_t j0 = (size_t)c * Lb;
+    const size_t stride = (size_t)gpb * kThreads;
+    fq acc[1] = {fq_zero()};
+    size_t i = (size_t)wl * kThreads + threadIdx.x;
+    if (DB) {
+        fq A[1 << M], B[1 << M];
+        if (i < Lb) mf_load<M>(A, src, Lout, j0 + i);
+        while (i < Lb) {
+            size_t n = i + stride;
+            if (n < Lb) mf_load<M>(B, src, Lout, j0 + n);
+            asm volatile("" ::: "memory"); // keep the prefetch above the arithmetic
+            fq o = mf_tree<M>(A, ch);
+            fq_store(dst + j0 + i, o);
+            acc[0] = fq_add(acc[0], o);
+            i = n;
+            if (i >= Lb) break;
+            n = i + stride;
+            if (n < Lb) mf_load<M>(A, src, Lout, j0 + n);
+            asm volatile("" ::: "memory");
+            o = mf_tree<M>(B, ch);
+            fq_store(dst + j0 + i, o);
+            acc[0] = fq_add(acc[0], o);
+            i = n;
+        }
+    } else {
+        for (; i < Lb; i += stride) {
+            fq A[1 << M];
+            mf_load<M>(A, src, Lout, j0 + i);
+            fq o = mf_tree<M>(A, ch);
+            fq_store(dst + j0 + i, o);
+            acc[0] = fq_add(acc[0], o);
+        }
+    }
+    block_sum_store<1>(acc, partials);
+}
+
+// Same pass with the tree replaced by ONE inner product with the eq weights
+//   T'[j] = sum_b eq(r, b) * T[b * L' + j],   eq(r, b) = prod_l (b_l ? r_l : 1 - r_l), b_0 = MSB
+// accumulated unreduced in radix 2^28 (fq_dev.hpp) and reduced once: (64 + 72/2^M) limb products per
+// input entry instead of ~119-127 for the tree, which moves this kernel from ALU-bound to HBM-bound.
+// W.w[b] = eq(r,b) * 2^280 mod p as 10 x 28-bit limbs (made on the host).  Same field values as the
+// tree: both are exact.
+template <int M> struct W28 { u32 w[1 << M][10]; };
+
+// Loads are software-pipelined through two register buffers of G elements: while group g is being
+// multiplied into the accumulators, group g+1 (or group 0 of the next grid-stride step) is in flight.
+template <int G>
+__device__ __forceinline__ void lazy_load(fq (&buf)[G], const fq* __restrict__ src, size_t Lout, size_t j, int g) {
+#pragma unroll
+    for (int b = 0; b < G; ++b) buf[b] = fq_load_stream(src + (size_t)(g * G + b) * Lout + j);
+    asm volatile("" ::: "memory"); // keep the loads where they are issued
+}
+template <int M, int G>
+__device__ __forceinline__ void lazy_mac(u64 (&acc)[20], const fq (&buf)[G], const W28<M>& W, int g) {
+#pragma unroll
+    for (int b = 0; b < G; ++b) fq28_mac(acc, buf[b], W.w[g * G + b]);
+}
+
+template <int M, int G>
+__global__ void __launch_bounds__(kThreads) k_multifold_lazy(const fq* __restrict__ src, fq* __restrict__ dst, size_t Lout, W28<M> W,
+                                                              int log_ob, fq* __restrict__ partials) {
+    constexpr int NB = 1 << M, NG = NB / G;
+    static_assert(NB % G == 0 && (NG == 1 || NG % 2 == 0), "group count must be 1 or even");
+    const unsigned gpb = gridDim.x >> log_ob;
+    const unsigned c = blockIdx.x / gpb, wl = blockIdx.x % gpb;
+    const size_t Lb = Lout >> log_ob;
+    const size_t j0 = (size_t)c * Lb;
+    const size_t stride = (size_t)gpb * kThreads;
+    fq acc1[1] = {fq_zero()};
+    size_t i = (size_t)wl * kThreads + threadIdx.x;
+    fq A[G], B[G];
+    if (i < Lb) lazy_load<G>(A, src, Lout, j0 + i, 0);
+    if (NG == 1) {
+        // one group per output: alternate the buffers between consecutive grid-stride steps
+        while (i < Lb) {
+            size_t n = i + stride;
+            if (n < Lb) lazy_load<G>(B, src, Lout, j0 + n, 0);
+            u64 acc[20];
+#pragma unroll
+            for (int k = 0; k < 20; ++k) acc[k] = 0;
+            lazy_mac<M, G>(acc, A, W, 0);
+            fq o = fq28_redc(acc);
+            fq_store(dst + j0 + i, o);
+            acc1[0] = fq_add(acc1[0], o);
+            i = n;
+            if (i >= Lb) break;
+            n = i + stride;
+            if (n < Lb) lazy_load<G>(A, src, Lout, j0 + n, 0);
+#pragma unroll
+            for (int k = 0; k < 20; ++k) acc[k] = 0;
+            lazy_mac<M, G>(acc, B, W, 0);
+            o = fq28_redc(acc);
+            fq_store(dst + j0 + i, o);
+            acc1[0] = fq_add(acc1[0], o);
+            i = n;
+        }
+    } else {
+        while (i < Lb) {
+            const size_t n = i + stride;
+            u64 acc[20];
+#pragma unroll
+            for (int k = 0; k < 20; ++k) acc[k] = 0;
+#pragma unroll
+            for (int g = 0; g < NG; g += 2) {
+                lazy_load<G>(B, src, Lout, j0 + i, g + 1);
+                lazy_mac<M, G>(acc, A, W, g);
+                if (g + 2 < NG) lazy_load<G>(A, src, Lout, j0 + i, g + 2);
+                else if (n < Lb) lazy_load<G>(A, src, Lout, j0 + n, 0);
+                lazy_mac<M, G>(acc, B, W, g + 1);
+            }
+            fq o = fq28_redc(acc);
+            fq_store(dst + j0 + i, o);
+            acc1[0] = fq_add(acc1[0], o);
+            i = n;
+        }
+    }
+    block_sum_store<1>(acc1, partials);
+}
+
+// second stage for the kernels above: out[c] = sum of the gpb partials of block c (fixed order)
+__global__ void __launch_bounds__(kThreads) k_reduce_groups(const fq* __restrict__ partials, int gpb, fq* __restrict__ out) {
+    fq acc[1] = {fq_zero()};
+    const fq* __restrict__ p = partials + (size_t)blockIdx.x * gpb;
+    for (int b = threadIdx.x; b < gpb; b += kThreads) acc[0] = fq_add(acc[0], fq_load(p + b));
+    block_sum_store<1>(acc, out);
 }
 
 // ---- plain fold of an arbitrary variable (partially_evaluate((v, r))) --------------------
@@ -264,14 +394,66 @@ static inline fq to_fq(const uint64_t r[4]) {
     return f;
 }
 
-int launch_round_sums(const void* T, size_t half, void* partials, hipStream_t st) {
-    int g = grid_for(half);
-    hipLaunchKernelGGL(k_round_sums, dim3(g), dim3(kThreads), 0, st, (const fq*)T, half, (fq*)partials);
+// grid for a pass whose work is cut into 2^log_ob blocks of Lb entries: a multiple of 2^log_ob
+static inline int grid_blocks(size_t Lb, int log_ob) {
+    size_t per = (Lb + kThreads - 1) / kThreads;
+    size_t cap = (size_t)kMaxBlocks >> log_ob;
+    if (per > cap) per = cap;
+    if (per < 1) per = 1;
+    return (int)(per << log_ob);
+}
+int launch_block_sums(const void* T, size_t L, int log_ob, void* partials, void* out, hipStream_t st) {
+    int g = grid_blocks(L >> log_ob, log_ob);
+    hipLaunchKernelGGL(k_block_sums, dim3(g), dim3(kThreads), 0, st, (const fq*)T, L, log_ob, (fq*)partials);
+    hipLaunchKernelGGL(k_reduce_groups, dim3(1 << log_ob), dim3(kThreads), 0, st, (const fq*)partials, g >> log_ob, (fq*)out);
     return g;
 }
-int launch_fold_sums(const void* src, void* dst, size_t q, const uint64_t r[4], void* partials, hipStream_t st) {
-    int g = grid_for(q);
-    hipLaunchKernelGGL(k_fold_sums, dim3(g), dim3(kThreads), 0, st, (const fq*)src, (fq*)dst, q, to_fq(r), (fq*)partials);
+template <int M>
+static int launch_multifold_m(const void* src, void* dst, size_t Lout, const uint64_t* r, int log_ob, bool db, void* partials, hipStream_t st) {
+    Chal<M> ch;
+    for (int l = 0; l < M; ++l) ch.r[l] = to_fq(r + 4 * l);
+    int g = grid_blocks(Lout >> log_ob, log_ob);
+    if (db) hipLaunchKernelGGL((k_multifold<M, true>), dim3(g), dim3(kThreads), 0, st, (const fq*)src, (fq*)dst, Lout, ch, log_ob, (fq*)partials);
+    else hipLaunchKernelGGL((k_multifold<M, false>), dim3(g), dim3(kThreads), 0, st, (const fq*)src, (fq*)dst, Lout, ch, log_ob, (fq*)partials);
+    return g;
+}
+template <int M, int G>
+static int launch_multifold_lazy_m(const void* src, void* dst, size_t Lout, const uint32_t* w28, int log_ob, void* partials, hipStream_t st) {
+    W28<M> W;
+    for (int b = 0; b < (1 << M); ++b)
+        for (int j = 0; j < 10; ++j) W.w[b][j] = w28[b * 10 + j];
+    int g = grid_blocks(Lout >> log_ob, log_ob);
+    hipLaunchKernelGGL((k_multifold_lazy<M, G>), dim3(g), dim3(kThreads), 0, st, (const fq*)src, (fq*)dst, Lout, W, log_ob, (fq*)partials);
+    return g;
+}
+int launch_multifold_lazy(int m, int group, const void* src, void* dst, size_t Lout, const uint32_t* w28, int log_ob, void* partials,
+                          void* out, hipStream_t st) {
+    int g = 0;
+    const bool g2 = group == 2;
+    switch (m) {
+        case 1: g = launch_multifold_lazy_m<1, 2>(src, dst, Lout, w28, log_ob, partials, st); break;
+        case 2: g = g2 ? launch_multifold_lazy_m<2, 2>(src, dst, Lout, w28, log_ob, partials, st)
+                       : launch_multifold_lazy_m<2, 4>(src, dst, Lout, w28, log_ob, partials, st); break;
+        case 3: g = g2 ? launch_multifold_lazy_m<3, 2>(src, dst, Lout, w28, log_ob, partials, st)
+                       : launch_multifold_lazy_m<3, 4>(src, dst, Lout, w28, log_ob, partials, st); break;
+        case 4: g = g2 ? launch_multifold_lazy_m<4, 2>(src, dst, Lout, w28, log_ob, partials, st)
+                       : launch_multifold_lazy_m<4, 4>(src, dst, Lout, w28, log_ob, partials, st); break;
+        default: return -1;
+    }
+    hipLaunchKernelGGL(k_reduce_groups, dim3(1 << log_ob), dim3(kThreads), 0, st, (const fq*)partials, g >> log_ob, (fq*)out);
+    return g;
+}
+int launch_multifold(int m, const void* src, void* dst, size_t Lout, const uint64_t* r, int log_ob, bool db, void* partials, void* out,
+                     hipStream_t st) {
+    int g = 0;
+    switch (m) {
+        case 1: g = launch_multifold_m<1>(src, dst, Lout, r, log_ob, db, partials, st); break;
+        case 2: g = launch_multifold_m<2>(src, dst, Lout, r, log_ob, db, partials, st); break;
+        case 3: g = launch_multifold_m<3>(src, dst, Lout, r, log_ob, db, partials, st); break;
+        case 4: g = launch_multifold_m<4>(src, dst, Lout, r, log_ob, false, partials, st); break;
+        default: return -1;
+    }
+    hipLaunchKernelGGL(k_reduce_groups, dim3(1 << log_ob), dim3(kThreads), 0, st, (const fq*)partials, g >> log_ob, (fq*)out);
     return g;
 }
 void launch_fold_var(const void* src, void* dst, size_t n_out, int log_s, const uint64_t r[4], hipStream_t st) {

@@ -24,6 +24,7 @@ using zkh::Fq;
 namespace {
 constexpr size_t kElem = 32;
 constexpr size_t kChunkElems = (size_t)1 << 21; // 64 MiB staging chunks for byte conversion
+constexpr size_t kSums = 16;                    // 2^kMaxFoldBatch block sums per pass
 
 inline bool is_pow2(size_t n) { return n && !(n & (n - 1)); }
 inline unsigned ilog2(size_t n) {
@@ -55,8 +56,12 @@ struct zk_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     void* partials = nullptr;   // kMaxBlocks * 3 elements
-    void* sums_dev = nullptr;   // 3 elements
-    uint64_t* sums_host = nullptr; // pinned, 3 elements
+    void* sums_dev = nullptr;   // kSums elements
+    uint64_t* sums_host = nullptr; // pinned, kSums elements
+    int fold_batch = 3;          // rounds bound per device pass (1..kMaxFoldBatch)
+    bool double_buffer = false;  // register double-buffering in k_multifold (tree variant)
+    bool lazy = true;            // inner-product form with one reduction per output (k_multifold_lazy)
+    int lazy_group = 4;          // elements per register load buffer in k_multifold_lazy (2 or 4)
     void* work[2] = {nullptr, nullptr};
     size_t work_cap[2] = {0, 0}; // bytes
     void* stage = nullptr;       // kChunkElems elements
@@ -74,6 +79,7 @@ struct zk_mle {
     void* d;
     size_t len;
     bool owned;
+    int device; // copy of ctx->device: freeing a table must not touch a context that is already gone
 };
 
 #define HIPCHK(ctx, call)                                                                           \
@@ -150,9 +156,46 @@ int fetch_sums(zk_ctx* c, int nblocks, int ns, Fq* out) {
     return ZK_OK;
 }
 
+// device->host of the ns block sums a launch_block_sums / launch_multifold left in sums_dev
+int fetch_block_sums(zk_ctx* c, int ns, Fq* out) {
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(c->sums_host, c->sums_dev, (size_t)ns * kElem, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int s = 0; s < ns; ++s) out[s] = zkh::load(c->sums_host + 4 * s);
+    return ZK_OK;
+}
+
+// eq(r, b) * 2^280 mod p for all b < 2^m as 10 x 28-bit limbs each; r[l] (Montgomery, 4 limbs each)
+// belongs to bit (m-1-l) of b: variable 0 is the most significant index bit (evaluation_form.rs:40-42)
+void eq_weights28(const uint64_t* rs, unsigned m, uint32_t* w28) {
+    Fq eq[1 << zkk::kMaxFoldBatch];
+    eq[0] = zkh::one();
+    unsigned n = 1;
+    for (unsigned l = 0; l < m; ++l) { // append variable l as the new least significant bit
+        const Fq r = zkh::load(rs + 4 * l), one_minus_r = zkh::sub(zkh::one(), r);
+        for (unsigned b = n; b-- > 0;) {
+            eq[2 * b + 1] = zkh::mul(eq[b], r);
+            eq[2 * b] = zkh::mul(eq[b], one_minus_r);
+        }
+        n *= 2;
+    }
+    // eq[b] holds eq*2^256 mod p; one more Montgomery product by (2^24 in Montgomery form) gives the
+    // plain integer eq * 2^280 mod p
+    const Fq two24 = zkh::from_u64((uint64_t)1 << 24);
+    for (unsigned b = 0; b < n; ++b) {
+        const Fq v = zkh::mul(eq[b], two24);
+        for (int j = 0; j < 10; ++j) {
+            const unsigned bit = 28 * j, w = bit / 64, sh = bit % 64;
+            uint64_t x = v.l[w] >> sh;
+            if (sh > 36 && w + 1 < 4) x |= v.l[w + 1] << (64 - sh);
+            w28[b * 10 + j] = (uint32_t)(x & 0x0fffffffu);
+        }
+    }
+}
+
 int new_mle(zk_ctx* c, size_t len, zk_mle** out) {
     if (!is_pow2(len)) return ZK_E_NOT_POW2; // evaluation_form.rs:23-27
-    zk_mle* m = new (std::nothrow) zk_mle{c, nullptr, len, true};
+    zk_mle* m = new (std::nothrow) zk_mle{c, nullptr, len, true, c->device};
     if (!m) return ZK_E_ALLOC;
     hipError_t e = hipMalloc(&m->d, len * kElem);
     if (e != hipSuccess) {
@@ -225,8 +268,8 @@ int zk_ctx_create(int device_id, zk_ctx** out) {
     if (fail(hipSetDevice(device_id), "hipSetDevice") ||
         fail(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking), "hipStreamCreate") ||
         fail(hipMalloc(&c->partials, (size_t)zkk::kMaxBlocks * 3 * kElem), "hipMalloc partials") ||
-        fail(hipMalloc(&c->sums_dev, 3 * kElem), "hipMalloc sums") ||
-        fail(hipHostMalloc((void**)&c->sums_host, 3 * kElem, hipHostMallocDefault), "hipHostMalloc sums")) {
+        fail(hipMalloc(&c->sums_dev, kSums * kElem), "hipMalloc sums") ||
+        fail(hipHostMalloc((void**)&c->sums_host, kSums * kElem, hipHostMallocDefault), "hipHostMalloc sums")) {
         zk_ctx_destroy(c);
         return rc;
     }
@@ -328,7 +371,7 @@ int zk_mle_wrap_device(zk_ctx* c, void* dptr, size_t len, zk_mle** out) {
     if (!c || !dptr || !out) return ZK_E_ARG;
     if (!is_pow2(len)) return ZK_E_NOT_POW2;
     if ((uintptr_t)dptr % 16) return ZK_E_ARG; // 16-byte vector loads
-    zk_mle* m = new (std::nothrow) zk_mle{c, dptr, len, false};
+    zk_mle* m = new (std::nothrow) zk_mle{c, dptr, len, false, c->device};
     if (!m) return ZK_E_ALLOC;
     *out = m;
     return ZK_OK;
@@ -373,7 +416,7 @@ int zk_mle_clone(const zk_mle* src, zk_mle** out) {
 void zk_mle_free(zk_mle* m) {
     if (!m) return;
     if (m->owned && m->d) {
-        (void)hipSetDevice(m->ctx->device);
+        (void)hipSetDevice(m->device);
         (void)hipFree(m->d);
     }
     delete m;
@@ -463,14 +506,12 @@ int zk_mle_round_sums(const zk_mle* m, uint64_t out[8]) {
     zk_ctx* c = m->ctx;
     int rc = set_device(c);
     if (rc) return rc;
-    int g;
     {
-        ProfScope ps(c, ZK_K_ROUND_SUMS, (uint64_t)m->len * 32);
-        g = zkk::launch_round_sums(m->d, m->len / 2, c->partials, c->stream);
+        ProfScope ps(c, ZK_K_BLOCK_SUMS, (uint64_t)m->len * 32);
+        zkk::launch_block_sums(m->d, m->len, 1, c->partials, c->sums_dev, c->stream);
     }
-    HIPCHK(c, hipGetLastError());
     Fq e[2];
-    if ((rc = fetch_sums(c, g, 2, e))) return rc;
+    if ((rc = fetch_block_sums(c, 2, e))) return rc;
     prof_collect(c);
     zkh::store(out, e[0]);
     zkh::store(out + 4, e[1]);
@@ -495,49 +536,74 @@ int zk_sumcheck_prove_mle(zk_ctx* c, const zk_mle* poly, int absorb_table, zk_tr
         if (rc) return rc;
     }
 
-    Fq e[2];
     if (n == 0) { // zero variables: no rounds; initial_claim_sum = the single entry
         HIPCHK(c, hipMemcpyAsync(c->sums_host, poly->d, kElem, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         std::memcpy(claim_out, c->sums_host, kElem);
         return ZK_OK;
     }
-    if (n >= 2) {
-        if ((rc = ensure_work(c, 0, len / 2 * kElem))) return rc;
-        if (n >= 3 && (rc = ensure_work(c, 1, len / 4 * kElem))) return rc;
-    }
 
-    int g;
+    // Batched rounds (kernels.hip): S = 2^m block sums of the current table; the host runs m rounds
+    // on S (half sums of S == half sums of the table, prover.rs:108-116); one device pass then binds
+    // those m variables and produces the next batch's block sums.
+    const unsigned M = (unsigned)c->fold_batch;
+    unsigned ell = n;                       // variables left in the device table
+    unsigned m = std::min(M, ell);
+    Fq S[kSums];
     {
-        ProfScope ps(c, ZK_K_ROUND_SUMS, (uint64_t)len * 32);
-        g = zkk::launch_round_sums(poly->d, len / 2, c->partials, c->stream);
+        ProfScope ps(c, ZK_K_BLOCK_SUMS, (uint64_t)len * 32);
+        zkk::launch_block_sums(poly->d, len, (int)m, c->partials, c->sums_dev, c->stream);
     }
-    HIPCHK(c, hipGetLastError());
-    if ((rc = fetch_sums(c, g, 2, e))) return rc;
-    zkh::store(claim_out, zkh::add(e[0], e[1])); // evaluation_sum(), prover.rs:170
+    if ((rc = fetch_block_sums(c, 1 << m, S))) return rc;
+    {
+        Fq total = zkh::zero();
+        for (unsigned b = 0; b < (1u << m); ++b) total = zkh::add(total, S[b]);
+        zkh::store(claim_out, total); // evaluation_sum(), prover.rs:170
+    }
 
     const void* cur = poly->d;
-    size_t curlen = len;
-    for (unsigned k = 0; k < n; ++k) {
-        Fq claimed = zkh::add(e[0], e[1]);  // prover.rs:118
-        Fq c1 = zkh::sub(e[1], e[0]);       // interpolate([0,1],[e0,e1]) = [e0, e1-e0], :120-123
-        tr->append_fq(claimed);             // :126-129
-        tr->append_fq(e[0]);
-        tr->append_fq(c1);
-        Fq r = tr->sample();                // :141-144
-        zkh::store(coeffs_out + 8 * k, e[0]);
-        zkh::store(coeffs_out + 8 * k + 4, c1);
-        if (challenges_out) zkh::store(challenges_out + 4 * k, r);
-        if (k + 1 == n) break; // the last fold's output (one entry) is never used by the prover
-        void* dst = c->work[k & 1];
-        {
-            ProfScope ps(c, ZK_K_FOLD_SUMS, (uint64_t)curlen * 48);
-            g = zkk::launch_fold_sums(cur, dst, curlen / 4, r.l, c->partials, c->stream);
+    unsigned k = 0; // round index
+    int pass = 0;
+    for (;;) {
+        uint64_t rs[4 * zkk::kMaxFoldBatch];
+        unsigned slen = 1u << m;
+        for (unsigned t = 0; t < m; ++t, ++k) {
+            const unsigned half = slen / 2;
+            Fq e0 = zkh::zero(), e1 = zkh::zero();
+            for (unsigned b = 0; b < half; ++b) { e0 = zkh::add(e0, S[b]); e1 = zkh::add(e1, S[half + b]); }
+            Fq claimed = zkh::add(e0, e1);      // prover.rs:118
+            Fq c1 = zkh::sub(e1, e0);           // interpolate([0,1],[e0,e1]) = [e0, e1-e0], :120-123
+            tr->append_fq(claimed);             // :126-129
+            tr->append_fq(e0);
+            tr->append_fq(c1);
+            Fq r = tr->sample();                // :141-144
+            zkh::store(coeffs_out + 8 * k, e0);
+            zkh::store(coeffs_out + 8 * k + 4, c1);
+            if (challenges_out) zkh::store(challenges_out + 4 * k, r);
+            zkh::store(rs + 4 * t, r);
+            for (unsigned b = 0; b < half; ++b) S[b] = zkh::add(S[b], zkh::mul(zkh::sub(S[half + b], S[b]), r)); // evaluation_form.rs:184
+            slen = half;
         }
-        HIPCHK(c, hipGetLastError());
-        if ((rc = fetch_sums(c, g, 2, e))) return rc;
+        ell -= m;
+        if (ell == 0) break; // the fully folded table (one entry) is never used by the prover
+        const unsigned m_next = std::min(M, ell);
+        const size_t lout = (size_t)1 << ell;
+        if ((rc = ensure_work(c, pass & 1, lout * kElem))) return rc;
+        void* dst = c->work[pass & 1];
+        {
+            ProfScope ps(c, ZK_K_MULTIFOLD, (uint64_t)(lout << m) * 32 + (uint64_t)lout * 32);
+            if (c->lazy && m >= 2) {
+                uint32_t w28[(1 << zkk::kMaxFoldBatch) * 10];
+                eq_weights28(rs, m, w28);
+                zkk::launch_multifold_lazy((int)m, c->lazy_group, cur, dst, lout, w28, (int)m_next, c->partials, c->sums_dev, c->stream);
+            } else {
+                zkk::launch_multifold((int)m, cur, dst, lout, rs, (int)m_next, c->double_buffer, c->partials, c->sums_dev, c->stream);
+            }
+        }
+        if ((rc = fetch_block_sums(c, 1 << m_next, S))) return rc;
         cur = dst;
-        curlen /= 2;
+        m = m_next;
+        ++pass;
     }
     prof_collect(c);
     return ZK_OK;
@@ -660,6 +726,14 @@ int zk_sumcheck_verify_mle(zk_ctx* c, const zk_mle* poly, const uint64_t claim[4
 }
 
 // ---- measurement ----------------------------------------------------------------------------------
+int zk_ctx_set_fold_batch(zk_ctx* c, int rounds_per_pass, int variant) {
+    if (!c || rounds_per_pass < 1 || rounds_per_pass > zkk::kMaxFoldBatch || variant < 0 || variant > 3) return ZK_E_ARG;
+    c->fold_batch = rounds_per_pass;
+    c->lazy = variant == 0 || variant == 3;
+    c->lazy_group = variant == 3 ? 2 : 4;
+    c->double_buffer = variant == 2;
+    return ZK_OK;
+}
 int zk_prof_enable(zk_ctx* c, int on) {
     if (!c) return ZK_E_ARG;
     c->prof_on = on != 0;
