@@ -211,7 +211,7 @@ def bench_single(args, ctx, zk_amd, np):
     dom = kernels[kernel]
     roofline = {
         "bound": "hbm", "kernel": kernel, "achieved": dom["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": dom["achieved_GBs"] / HBM_PEAK_GBS, "traffic": None,
+        "frac": dom["achieved_GBs"] / HBM_PEAK_GBS, "traffic": pmc_traffic(kernel, args.log_n),
         "note": "achieved = algorithmic bytes of all launches of the kernel in the timed steps / their summed "
                 "HIP-event durations (multifold: 32 B per input entry read + 32 B per output entry written; "
                 "fold4_eval3: 48 B per input entry per table)",
@@ -230,6 +230,23 @@ def bench_single(args, ctx, zk_amd, np):
         res["absorb_ms"] = absorb_ms
         res["inclusive_ms"] = absorb_ms + ms_per_step
     return res
+
+
+def pmc_traffic(kernel: str, log_n: int):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 counter passes of this same
+    command (profiles/*hbm_traffic.json; counters cannot be read from inside the process).  None
+    when no committed pass matches the workload."""
+    import glob
+
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*hbm_traffic.json")), reverse=True):
+        try:
+            with open(path) as f:
+                d = json.load(f)
+        except (OSError, ValueError):
+            continue
+        if d.get("log_n") == log_n and kernel in d.get("kernels", {}):
+            return d["kernels"][kernel]["bytes_per_launch"]
+    return None
 
 
 def absorb_table(zk_amd, ctx, poly, transcript):

@@ -121,7 +121,7 @@ int zk_sumcheck_verify_mle(zk_ctx *ctx, const zk_mle *poly, const uint64_t claim
                            size_t n_rounds, int *ok_out);
 
 /* ---- tuning / measurement hooks (no reference counterpart) ---------------------------- */
-/* Rounds bound per device pass by the single-MLE prover (1..4, default 3) and the fold kernel
+/* Rounds bound per device pass by the single-MLE prover (1..4, default 4) and the fold kernel
  * variant: 0 = inner product with eq weights, one reduction per output (default); 1 = fold tree;
  * 2 = fold tree with register double-buffering; 3 = as 0 with 2-element load groups.  Proof bytes do not
  * depend on either. */

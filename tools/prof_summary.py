@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Summarise a rocprofv3 CSV output directory into the small text files kept under profiles/.
+
+  prof_summary.py stats <dir>          per-kernel launches / total / avg / min / max (from *_kernel_trace.csv)
+  prof_summary.py pmc   <dir>          per-kernel counter sums and the largest launch's values (from *_counter_collection.csv)
+
+HBM bytes from the PMC counters follow /opt/skills/guides/MI355X_MICROARCH.md (HBM section):
+FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports exactly half of the bytes of a
+16-B-per-lane coalesced streaming read, so reads = 2 * FETCH_SIZE * 1024; WRITE_SIZE is exact.
+"""
+import csv
+import glob
+import os
+import re
+import sys
+from collections import defaultdict
+
+
+def short(name: str) -> str:
+    m = re.match(r"(?:void )?(?:zkk::)?([A-Za-z0-9_]+(?:<[^>]*>)?)", name)
+    return m.group(1) if m else name[:40]
+
+
+def find(d, suffix):
+    hits = glob.glob(os.path.join(d, "**", "*" + suffix), recursive=True)
+    if not hits:
+        raise SystemExit(f"no *{suffix} under {d}")
+    return hits
+
+
+def stats(d):
+    per = defaultdict(list)
+    for f in find(d, "_kernel_trace.csv"):
+        with open(f, newline="") as fh:
+            for r in csv.DictReader(fh):
+                per[short(r["Kernel_Name"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    tot = sum(sum(v) for v in per.values())
+    print(f"{'kernel':44s} {'calls':>6s} {'total_us':>12s} {'avg_us':>10s} {'min_us':>10s} {'max_us':>10s} {'%':>6s}")
+    for k, v in sorted(per.items(), key=lambda kv: -sum(kv[1])):
+        print(f"{k:44s} {len(v):6d} {sum(v):12.1f} {sum(v) / len(v):10.1f} {min(v):10.1f} {max(v):10.1f} {100 * sum(v) / tot:6.1f}")
+
+
+def pmc(d):
+    rows = defaultdict(lambda: defaultdict(list))  # kernel -> counter -> [(dispatch, value, dur_us)]
+    for f in find(d, "_counter_collection.csv"):
+        with open(f, newline="") as fh:
+            for r in csv.DictReader(fh):
+                dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+                rows[short(r["Kernel_Name"])][r["Counter_Name"]].append((int(r["Dispatch_Id"]), float(r["Counter_Value"]), dur))
+    for k, ctrs in sorted(rows.items()):
+        for cname, vals in sorted(ctrs.items()):
+            big = max(vals, key=lambda t: t[1])
+            line = f"{k:40s} {cname:22s} launches {len(vals):4d}  sum {sum(v for _, v, _ in vals):.6g}  largest launch {big[1]:.6g} (dispatch {big[0]})"
+            if cname == "FETCH_SIZE":
+                line += f"  => HBM read {2 * big[1] * 1024 / 1e9:.4f} GB (2 x FETCH_SIZE KiB, gfx950 correction)"
+            if cname == "WRITE_SIZE":
+                line += f"  => HBM write {big[1] * 1024 / 1e9:.4f} GB"
+            print(line)
+
+
+if __name__ == "__main__":
+    if len(sys.argv) != 3 or sys.argv[1] not in ("stats", "pmc"):
+        raise SystemExit(__doc__)
+    (stats if sys.argv[1] == "stats" else pmc)(sys.argv[2])

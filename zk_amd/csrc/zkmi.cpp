@@ -58,7 +58,7 @@ struct zk_ctx {
     void* partials = nullptr;   // kMaxBlocks * 3 elements
     void* sums_dev = nullptr;   // kSums elements
     uint64_t* sums_host = nullptr; // pinned, kSums elements
-    int fold_batch = 3;          // rounds bound per device pass (1..kMaxFoldBatch)
+    int fold_batch = 4;          // rounds bound per device pass (1..kMaxFoldBatch)
     bool double_buffer = false;  // register double-buffering in k_multifold (tree variant)
     bool lazy = true;            // inner-product form with one reduction per output (k_multifold_lazy)
     int lazy_group = 4;          // elements per register load buffer in k_multifold_lazy (2 or 4)
