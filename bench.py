@@ -38,6 +38,9 @@ def parse():
     ap.add_argument("--cpu-log-n", type=int, default=24, help="bounded CPU sample size (2^k entries)")
     ap.add_argument("--fold-batch", type=int, default=0, help="rounds bound per device pass (0 = library default)")
     ap.add_argument("--fold-variant", type=int, default=0, help="0 eq-weight inner product, 1 tree, 2 tree+double buffer")
+    ap.add_argument("--weak", action="store_true", help="multi-GPU: 2^log_n entries PER GPU instead of in total")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for the multi-GPU exchange")
+    ap.add_argument("--shared-device", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
     return ap.parse_args()
 
 
@@ -95,23 +98,24 @@ def main():
         import torch.distributed as dist_mod
 
         dist = dist_mod
+        if args.shared_device:
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
 
     def barrier():
         if dist is not None:
             dist.barrier()
 
-    ctx = zk_amd.Context(local_rank)
-    if args.fold_batch:
-        ctx.set_fold_batch(args.fold_batch, args.fold_variant)
-    n = 1 << args.log_n
-
     if world > 1:
-        from zk_amd.sharded import bench_sharded  # multi-GPU path: table sharded on the last-bound variables
-
-        result = bench_sharded(args, ctx, dist, rank, world)
+        result = bench_sharded(args, zk_amd, np, dist, rank, local_rank, world)
     else:
+        ctx = zk_amd.Context(local_rank)
+        if args.fold_batch:
+            ctx.set_fold_batch(args.fold_batch, args.fold_variant)
         result = bench_single(args, ctx, zk_amd, np)
 
     torch.cuda.synchronize()
@@ -130,7 +134,7 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": result["ms_per_step"],
         "higher_is_better": True,
-        "scaling": "strong" if world > 1 else "weak",
+        "scaling": "weak" if (world == 1 or args.weak) else "strong",
         "vs_baseline": None,
         "dtype": "u32x8 (254-bit Montgomery, BN254 Fq)",
         "data": "synthetic (seeded splitmix64, full-range field elements)",
@@ -230,6 +234,92 @@ def bench_single(args, ctx, zk_amd, np):
         res["absorb_ms"] = absorb_ms
         res["inclusive_ms"] = absorb_ms + ms_per_step
     return res
+
+
+def bench_sharded(args, zk_amd, np, dist, rank, local_rank, world):
+    """One rank per GPU; the 2^log_n-entry table is sharded on the variables bound last
+    (zk_amd/sharded.py).  Strong scaling by default (the metric's 2^28 entries in total)."""
+    import torch
+
+    from zk_amd import sharded
+
+    if args.workload != "mle":
+        raise SystemExit("multi-GPU bench: --workload mle only")
+    g = world.bit_length() - 1
+    if world != 1 << g:
+        raise SystemExit("world size must be a power of two")
+    log_total = args.log_n + (g if args.weak else 0)
+    n_local = 1 << (log_total - g)
+    ctx = sharded.torch_stream_context(local_rank)
+    if args.fold_batch:
+        ctx.set_fold_batch(args.fold_batch, args.fold_variant)
+    fold_batch = args.fold_batch or sharded.MAX_FOLD_BATCH
+    poly = zk_amd.MultiLinearPolynomial.generate(SEED, n_local, first=rank, step=world, ctx=ctx)
+    base = zk_amd.Transcript()
+    base.append(b"bench: table absorb skipped (sharded run; SURVEY.md H1)")
+
+    def step():
+        sh = sharded.DeviceShard(poly)
+        try:
+            return sharded.generate_round_polys_sharded(sh, base.clone(), world, dist, None, fold_batch)
+        finally:
+            sh.close()
+
+    for _ in range(args.warmup):
+        step()
+    ctx.prof_enable(True)
+    ctx.prof_collect()
+    ctx.prof_reset()
+    torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    last = None
+    for _ in range(args.steps):
+        last = step()
+    torch.cuda.synchronize()
+    dist.barrier()
+    dt = time.perf_counter() - t0
+    ctx.prof_collect()
+    ctx.prof_enable(False)
+    dev = torch.device("cuda", ctx.device_id) if dist.get_backend() == "nccl" else torch.device("cpu")
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    # every rank must hold the same proof: compare a digest of (claim, round polys, challenges)
+    import hashlib
+
+    digest = hashlib.sha256(b"".join(np.ascontiguousarray(a).tobytes() for a in last)).digest()
+    dg = torch.frombuffer(bytearray(digest), dtype=torch.uint8).to(torch.int64).to(dev)
+    lo, hi = dg.clone(), dg.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    same = bool(torch.equal(lo, hi))
+    ms_per_step = float(tmax.item()) * 1e3 / args.steps
+
+    kernels = {}
+    for name in ("block_sums", "multifold"):
+        p = ctx.prof_read(name)
+        if p["launches"]:
+            kernels[name] = {
+                "launches": p["launches"], "total_ms": p["ms"], "avg_ms": p["ms"] / p["launches"],
+                "alg_bytes_per_launch": p["alg_bytes"] / p["launches"],
+                "achieved_GBs": p["alg_bytes"] / (p["ms"] * 1e-3) / 1e9 if p["ms"] > 0 else None,
+            }
+    dom = kernels["multifold"]
+    roofline = {
+        "bound": "hbm", "kernel": "multifold", "achieved": dom["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": dom["achieved_GBs"] / HBM_PEAK_GBS, "traffic": None,
+        "note": "rank 0's launches (per GPU): algorithmic bytes of all launches of the kernel in the timed steps / "
+                "their summed HIP-event durations (32 B per input entry read + 32 B per output entry written)",
+    }
+    return {
+        "elems_per_s": (1 << log_total) / (ms_per_step * 1e-3), "ms_per_step": ms_per_step, "roofline": roofline,
+        "kernels": kernels, "proof_check": {"all_ranks_identical": same},
+        "config": {"workload": f"single-MLE sumcheck, 2^{log_total} entries sharded over {world} GPUs "
+                               f"(2^{log_total - g} per GPU, low-bit sharding)",
+                   "log_n": log_total, "field": "BN254 Fq", "parallelism": f"table-sharded x{world}",
+                   "exchange": f"all-gather of 2^m block sums per pass ({dist.get_backend()}), {fold_batch} rounds per pass",
+                   "transcript": "Keccak-256 on every host, one challenge per round"},
+    }
 
 
 def pmc_traffic(kernel: str, log_n: int):

@@ -56,6 +56,9 @@ const char *zk_version(void);
 
 /* ---- context ------------------------------------------------------------------------- */
 int zk_ctx_create(int device_id, zk_ctx **out);
+/* the same on a stream the caller owns (e.g. the current stream of the host framework that also
+ * runs the collectives), so kernels and collectives order on one stream without extra syncs */
+int zk_ctx_create_on_stream(int device_id, void *hip_stream, zk_ctx **out);
 void zk_ctx_destroy(zk_ctx *ctx); /* tables of this context may be freed afterwards, not used */
 /* the HIP stream (hipStream_t) every kernel of this context is launched on */
 void *zk_ctx_stream(zk_ctx *ctx);
@@ -79,6 +82,12 @@ int zk_mle_wrap_device(zk_ctx *ctx, void *device_ptr, size_t len, zk_mle **out);
 /* synthetic table generated on device: entry j = splitmix64 stream `seed`,
  * draws 4(first+j)+1 .. +4, little-endian 256 bits, mod p, to Montgomery.  No reference counterpart. */
 int zk_mle_generate(zk_ctx *ctx, uint64_t seed, uint64_t first, size_t len, zk_mle **out);
+/* as zk_mle_generate, local entry j = global entry first + j*step (step = number of shards) */
+int zk_mle_generate_strided(zk_ctx *ctx, uint64_t seed, uint64_t first, uint64_t step, size_t len, zk_mle **out);
+/* shard `rank` of `world` (power of two) of a host table of global_len entries: local entry j =
+ * global entry j*world + rank -- the table is sharded on the variables bound LAST, so
+ * every fold pair (j, j + N/2) of evaluation_form.rs:61-79 stays on one GPU */
+int zk_mle_upload_mont_shard(zk_ctx *ctx, const uint64_t *limbs, size_t global_len, int rank, int world, zk_mle **out);
 int zk_mle_clone(const zk_mle *src, zk_mle **out);                          /* #[derive(Clone)] :16 */
 void zk_mle_free(zk_mle *m);
 size_t zk_mle_len(const zk_mle *m);
@@ -111,6 +120,31 @@ int zk_sumcheck_prove_mle(zk_ctx *ctx, const zk_mle *poly, int absorb_table, zk_
 int zk_sumcheck_prove_sum2x2(zk_ctx *ctx, zk_mle *const tables[4], const uint64_t claim_mont[4],
                              zk_transcript *transcript, uint64_t *coeffs_out, uint64_t *challenges_out);
 
+/* ---- the same round loop in steps, for a table sharded over several GPUs ----------------
+ * generate_round_polys (sumcheck/src/prover.rs:45-155, MLE branch) cut at the points where ranks
+ * must exchange: device passes (zk_shard_*, asynchronous on the context stream) and the host part
+ * (zk_sumcheck_rounds_from_block_sums, no GPU needed).  zk_sumcheck_prove_mle is these same calls
+ * with world = 1.  The host framework all-gathers the 2^m block sums of every rank between the two
+ * (RCCL over xGMI; zk_amd/sharded.py uses torch.distributed), every rank runs the identical host part.
+ *
+ * sums: [world][2^m] elements, rank-major; the reduction runs m rounds on sum_q sums[q]:
+ *   coeffs_out m x 2, challenges_out m (may be NULL), total_out = sum of everything (may be NULL; the
+ *   first batch's total is SumCheckProof.initial_claim_sum), folded_out[world] (may be NULL) = each
+ *   rank's own 2^m sums folded at the m challenges -- once a local table is down to 2^m entries these
+ *   are the entries of the remaining log2(world)-variable table, which is finished by one more call
+ *   with world = 1, m = log2(world). */
+typedef struct zk_shard zk_shard;
+int zk_sumcheck_rounds_from_block_sums(zk_transcript *t, const uint64_t *sums, int world, int m, uint64_t *coeffs_out,
+                                       uint64_t *challenges_out, uint64_t *folded_out, uint64_t total_out[4]);
+int zk_shard_begin(zk_ctx *ctx, const zk_mle *local_table, zk_shard **out); /* the table is not modified */
+void zk_shard_end(zk_shard *s);
+int zk_shard_vars_left(const zk_shard *s);
+/* sums_dev_out (device, 2^m elements) = sums of the 2^m contiguous blocks of the current local table */
+int zk_shard_block_sums(zk_shard *s, int m, void *sums_dev_out);
+/* bind the top m variables at r[0..m) (m x partially_evaluate((0, r)), evaluation_form.rs:163-192) and
+ * leave the 2^m_next block sums of the result in sums_dev_out (m_next = 0: none) */
+int zk_shard_fold(zk_shard *s, int m, const uint64_t *r_mont, int m_next, void *sums_dev_out);
+
 /* ---- sumcheck verifier (sumcheck/src/verifier.rs) -- the parity harness ---------------- */
 /* partial_verify :29-62 (host only). */
 int zk_sumcheck_partial_verify(const uint64_t claim_mont[4], const uint64_t *coeffs, size_t n_rounds,
@@ -130,6 +164,8 @@ enum { ZK_K_BLOCK_SUMS = 0, ZK_K_MULTIFOLD = 1, ZK_K_FOLD = 2, ZK_K_EVAL3 = 3, Z
 /* per-kernel HIP-event timing of the launches made by the provers on this context */
 int zk_prof_enable(zk_ctx *ctx, int on);
 int zk_prof_reset(zk_ctx *ctx);
+/* synchronize the stream and account the launches the zk_shard_* calls recorded (the provers do this themselves) */
+int zk_prof_collect(zk_ctx *ctx);
 /* totals since the last reset: launches, elapsed ms (HIP events on the context stream) and
  * ALGORITHMIC bytes (block sums 32 B/entry; m-round fold 32 B per input entry + 32 B per
  * output entry; degree-2 kernels 32 B (eval) / 48 B (fold+eval) per input entry per table) */

@@ -1,0 +1,107 @@
+"""The sharded prover with the real DeviceShard (zk_shard_* of libzkmi.so) against the oracle's proof
+of the unsharded table, bit for bit.
+
+A GPU box for tests has ONE MI355X, and RCCL refuses two ranks on one device, so the multi-rank cases
+put every rank on cuda:0 and exchange through gloo; the single-rank case goes through the nccl (RCCL)
+backend so the device-tensor collective path that bench.py --gpus N uses is executed too."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import oracle_lib as O
+import zk_amd
+from zk_amd import sharded
+
+pytestmark = pytest.mark.gpu
+SEED = 0x5EED0000
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, backend, log_n, fold_batch, generated, outdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    try:
+        ctx = sharded.torch_stream_context(0)
+        n = 1 << log_n
+        if generated:  # made on the device, strided
+            local = zk_amd.MultiLinearPolynomial.generate(SEED, n // world, first=rank, step=world, ctx=ctx)
+        else:          # scattered from a host table
+            local = zk_amd.MultiLinearPolynomial.upload_shard(O.gen_table(SEED, 0, n), rank, world, ctx=ctx)
+        tr = zk_amd.Transcript()
+        sharded.absorb_table_sharded(local, tr, world, dist, None, chunk=1 << 8)
+        sh = sharded.DeviceShard(local)
+        claim, coeffs, ch = sharded.generate_round_polys_sharded(sh, tr, world, dist, None, fold_batch)
+        sh.close()
+        np.savez(os.path.join(outdir, f"r{rank}.npz"), claim=claim, coeffs=coeffs, ch=ch)
+    finally:
+        dist.destroy_process_group()
+
+
+def _check(tmp_path, world, log_n):
+    table = O.gen_table(SEED, 0, 1 << log_n)
+    oclaim, ocoeffs, och = O.sumcheck_prove(table)
+    for r in range(world):
+        d = np.load(tmp_path / f"r{r}.npz")
+        assert np.array_equal(d["claim"], oclaim), f"rank {r}: claim"
+        assert np.array_equal(d["coeffs"], ocoeffs), f"rank {r}: round polynomials"
+        assert np.array_equal(d["ch"], och), f"rank {r}: challenges"
+
+
+@pytest.mark.parametrize("world,log_n,fold_batch,generated", [(2, 14, 4, True), (4, 13, 3, False), (2, 3, 4, False), (8, 12, 4, True)])
+def test_sharded_ranks_on_one_gpu_gloo(tmp_path, world, log_n, fold_batch, generated):
+    mp.spawn(_worker, args=(world, _free_port(), "gloo", log_n, fold_batch, generated, str(tmp_path)), nprocs=world, join=True)
+    _check(tmp_path, world, log_n)
+
+
+def test_single_rank_through_rccl_backend(tmp_path):
+    mp.spawn(_worker, args=(1, _free_port(), "nccl", 12, 4, True, str(tmp_path)), nprocs=1, join=True)
+    _check(tmp_path, 1, 12)
+
+
+def test_device_shard_steps_match_oracle():
+    """zk_shard_block_sums / zk_shard_fold one by one, no process group."""
+    ctx = zk_amd.default_context()
+    n = 1 << 11
+    table = O.gen_table(SEED + 5, 0, n)
+    m = zk_amd.MultiLinearPolynomial(table, ctx=ctx)
+    sh = sharded.DeviceShard(m)
+    buf = sh.new_sums(16)
+    sh.block_sums(3, buf)
+    ctx.synchronize()
+    got = buf[:8].cpu().numpy().view(np.uint64)
+    for b in range(8):
+        assert np.array_equal(got[b], O.mle_sum(table[b * (n // 8):(b + 1) * (n // 8)]))
+    r = O.gen_table(99, 0, 3)
+    sh.fold(3, r, 2, buf)
+    ctx.synchronize()
+    t = table
+    for l in range(3):
+        t = O.mle_partially_evaluate(t, 0, r[l])
+    got = buf[:4].cpu().numpy().view(np.uint64)
+    q = t.shape[0] // 4
+    for b in range(4):
+        assert np.array_equal(got[b], O.mle_sum(t[b * q:(b + 1) * q]))
+    assert sh.vars_left() == 8
+    with pytest.raises(zk_amd.ZkError):
+        sh.fold(4, O.gen_table(1, 0, 4), 5, buf)  # more block sums than a pass supports
+    sh.fold(3, r, 4, buf)  # 8 -> 5 variables left
+    assert sh.vars_left() == 5
+    with pytest.raises(zk_amd.ZkError):
+        sh.fold(3, r, 3, buf)  # 3 + 3 > 5 variables left
+    ctx.synchronize()
+    sh.close()
+    assert np.array_equal(m.get_evaluation_points(), table)  # the caller's table is left unmodified

@@ -1,0 +1,111 @@
+"""Multi-rank logic of the sharded prover on CPU ranks (gloo, world_size 2 and 4).
+
+No GPU here, so each rank's LOCAL table work (block sums, fold of the top variables) is done by a
+stand-in shard backed by the CPU oracle -- test infrastructure standing in for DeviceShard.  What is
+under test is the product code around it: the low-bit sharding convention, the all-gather of the
+per-rank block sums, the host round function of libzkmi.so (zk_sumcheck_rounds_from_block_sums, which
+needs no GPU) and the host tail over the last log2(world) variables.  The result must equal the
+oracle's proof of the UNSHARDED table bit for bit.  tests/test_gpu_sharded.py runs the same loop with
+the real DeviceShard."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import oracle_lib as O
+import zk_amd
+from zk_amd import sharded
+
+SEED = 0x5EED0000
+
+
+class OracleShard:
+    """Stand-in for zk_amd.sharded.DeviceShard: the rank's local table as a numpy array, local passes
+    computed with the CPU oracle."""
+
+    def __init__(self, local_table: np.ndarray):
+        self.t = np.ascontiguousarray(local_table, dtype=np.uint64).reshape(-1, 4)
+
+    def vars_left(self):
+        return self.t.shape[0].bit_length() - 1
+
+    def new_sums(self, count):
+        return torch.zeros((count, 4), dtype=torch.int64)
+
+    def _sums(self, m, out):
+        nb = 1 << m
+        lb = self.t.shape[0] // nb
+        for b in range(nb):
+            out[b] = torch.from_numpy(O.mle_sum(self.t[b * lb:(b + 1) * lb]).view(np.int64))
+
+    def block_sums(self, m, out):
+        self._sums(m, out)
+
+    def fold(self, m, r, m_next, out):
+        for l in range(m):
+            self.t = O.mle_partially_evaluate(self.t, 0, r[l])
+        if m_next:
+            self._sums(m_next, out)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, log_n, fold_batch, outdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n = 1 << log_n
+        table = O.gen_table(SEED, 0, n)
+        local = table[rank::world]  # entry j of the shard = global entry j*world + rank
+        tr = zk_amd.Transcript()
+        tr.append(O.mle_to_bytes(table))  # generate_sumcheck_proof absorbs the whole table first
+        claim, coeffs, ch = sharded.generate_round_polys_sharded(OracleShard(local), tr, world, dist, None, fold_batch)
+        np.savez(os.path.join(outdir, f"r{rank}.npz"), claim=claim, coeffs=coeffs, ch=ch, digest=np.frombuffer(tr.peek_digest(), dtype=np.uint8))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,log_n,fold_batch", [(2, 10, 4), (2, 6, 3), (4, 9, 4), (2, 2, 4), (4, 3, 1)])
+def test_sharded_round_loop_matches_unsharded_oracle(tmp_path, world, log_n, fold_batch):
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, log_n, fold_batch, str(tmp_path)), nprocs=world, join=True)
+    table = O.gen_table(SEED, 0, 1 << log_n)
+    oclaim, ocoeffs, och = O.sumcheck_prove(table)
+    digests = []
+    for r in range(world):
+        d = np.load(tmp_path / f"r{r}.npz")
+        assert np.array_equal(d["claim"], oclaim), f"rank {r}: claim"
+        assert np.array_equal(d["coeffs"], ocoeffs), f"rank {r}: round polynomials"
+        assert np.array_equal(d["ch"], och), f"rank {r}: challenges"
+        digests.append(d["digest"].tobytes())
+    assert len(set(digests)) == 1  # every rank's transcript ended in the same state
+
+
+def test_rounds_from_block_sums_is_the_round_loop_on_a_small_table():
+    """world = 1, sums = the table itself: the host function alone is the whole MLE-branch round loop."""
+    for m in (1, 2, 3, 5):
+        table = O.gen_table(SEED + m, 0, 1 << m)
+        tr = zk_amd.Transcript()
+        tr.append(O.mle_to_bytes(table))
+        coeffs, ch, folded, total = sharded.rounds_from_block_sums(tr, table[None], want_folded=True, want_total=True)
+        oclaim, ocoeffs, och = O.sumcheck_prove(table)
+        assert np.array_equal(total, oclaim) and np.array_equal(coeffs, ocoeffs) and np.array_equal(ch, och)
+        pts = [och[i] for i in range(m)]
+        assert np.array_equal(folded[0], O.mle_evaluate(table, pts)[0])
+
+
+def test_rounds_from_block_sums_rejects_bad_shapes():
+    tr = zk_amd.Transcript()
+    with pytest.raises(ValueError):
+        sharded.rounds_from_block_sums(tr, np.zeros((1, 3, 4), dtype=np.uint64))
+    with pytest.raises(ValueError):
+        sharded.rounds_from_block_sums(tr, np.zeros((1, 1, 4), dtype=np.uint64))

@@ -27,6 +27,7 @@ SYMBOLS = [
     ("zk_last_error", C.c_char_p, [_VP]),
     ("zk_version", C.c_char_p, []),
     ("zk_ctx_create", C.c_int, [C.c_int, C.POINTER(_VP)]),
+    ("zk_ctx_create_on_stream", C.c_int, [C.c_int, _VP, C.POINTER(_VP)]),
     ("zk_ctx_destroy", None, [_VP]),
     ("zk_ctx_stream", _VP, [_VP]),
     ("zk_ctx_synchronize", C.c_int, [_VP]),
@@ -41,6 +42,8 @@ SYMBOLS = [
     ("zk_mle_upload_le32", C.c_int, [_VP, u8p, C.c_size_t, C.POINTER(_VP)]),
     ("zk_mle_wrap_device", C.c_int, [_VP, _VP, C.c_size_t, C.POINTER(_VP)]),
     ("zk_mle_generate", C.c_int, [_VP, C.c_uint64, C.c_uint64, C.c_size_t, C.POINTER(_VP)]),
+    ("zk_mle_generate_strided", C.c_int, [_VP, C.c_uint64, C.c_uint64, C.c_uint64, C.c_size_t, C.POINTER(_VP)]),
+    ("zk_mle_upload_mont_shard", C.c_int, [_VP, u64p, C.c_size_t, C.c_int, C.c_int, C.POINTER(_VP)]),
     ("zk_mle_clone", C.c_int, [_VP, C.POINTER(_VP)]),
     ("zk_mle_free", None, [_VP]),
     ("zk_mle_len", C.c_size_t, [_VP]),
@@ -53,11 +56,18 @@ SYMBOLS = [
     ("zk_mle_round_sums", C.c_int, [_VP, u64p]),
     ("zk_sumcheck_prove_mle", C.c_int, [_VP, _VP, C.c_int, _VP, u64p, u64p, u64p]),
     ("zk_sumcheck_prove_sum2x2", C.c_int, [_VP, C.POINTER(_VP), u64p, _VP, u64p, u64p]),
+    ("zk_sumcheck_rounds_from_block_sums", C.c_int, [_VP, u64p, C.c_int, C.c_int, u64p, u64p, u64p, u64p]),
+    ("zk_shard_begin", C.c_int, [_VP, _VP, C.POINTER(_VP)]),
+    ("zk_shard_end", None, [_VP]),
+    ("zk_shard_vars_left", C.c_int, [_VP]),
+    ("zk_shard_block_sums", C.c_int, [_VP, C.c_int, _VP]),
+    ("zk_shard_fold", C.c_int, [_VP, C.c_int, u64p, C.c_int, _VP]),
     ("zk_sumcheck_partial_verify", C.c_int, [u64p, u64p, C.c_size_t, C.c_size_t, _VP, C.POINTER(C.c_int), u64p, u64p]),
     ("zk_sumcheck_verify_mle", C.c_int, [_VP, _VP, u64p, u64p, C.c_size_t, C.POINTER(C.c_int)]),
     ("zk_ctx_set_fold_batch", C.c_int, [_VP, C.c_int, C.c_int]),
     ("zk_prof_enable", C.c_int, [_VP, C.c_int]),
     ("zk_prof_reset", C.c_int, [_VP]),
+    ("zk_prof_collect", C.c_int, [_VP]),
     ("zk_prof_read", C.c_int, [_VP, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     ("zk_bench_modmul", C.c_int, [_VP, C.c_int, C.c_int, C.POINTER(C.c_double)]),
 ]

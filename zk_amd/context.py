@@ -9,11 +9,19 @@ KERNELS = {"block_sums": 0, "multifold": 1, "fold": 2, "eval3": 3, "fold4_eval3"
 
 
 class Context:
-    def __init__(self, device_id: int = 0):
+    def __init__(self, device_id: int = 0, _stream=None):
         h = C.c_void_p()
-        check(lib().zk_ctx_create(device_id, C.byref(h)))
+        if _stream is None:
+            check(lib().zk_ctx_create(device_id, C.byref(h)))
+        else:
+            check(lib().zk_ctx_create_on_stream(device_id, C.c_void_p(_stream), C.byref(h)))
         self.h = h
         self.device_id = device_id
+
+    @classmethod
+    def on_stream(cls, device_id: int, hip_stream: int):
+        """Context that launches on a hipStream_t the caller owns (0 = the null stream)."""
+        return cls(device_id, _stream=hip_stream or 0)
 
     @property
     def stream(self) -> int:
@@ -34,6 +42,9 @@ class Context:
 
     def prof_reset(self):
         check(lib().zk_prof_reset(self.h))
+
+    def prof_collect(self):
+        check(lib().zk_prof_collect(self.h), self.h)
 
     def prof_read(self, kernel: str):
         n, ms, b = C.c_uint64(), C.c_double(), C.c_uint64()

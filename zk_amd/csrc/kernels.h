@@ -34,7 +34,7 @@ int launch_fold4_eval3(const void* const s[4], void* const d[4], size_t q, const
 void launch_fold4(const void* const s[4], void* const d[4], size_t half, const uint64_t r[4], hipStream_t st);
 void launch_from_le32(const void* in, void* out, size_t n, hipStream_t st);
 void launch_to_le32(const void* in, void* out, size_t n, hipStream_t st);
-void launch_generate(void* out, uint64_t seed, uint64_t first, size_t n, hipStream_t st);
+void launch_generate(void* out, uint64_t seed, uint64_t first, uint64_t step, size_t n, hipStream_t st);
 void launch_modmul_probe(void* io, int blocks, int iters, hipStream_t st);
 
 } // namespace zkk

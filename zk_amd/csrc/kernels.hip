@@ -351,11 +351,12 @@ __device__ __forceinline__ u64 splitmix64_at(u64 seed, u64 i) {
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
     return z ^ (z >> 31);
 }
-// synthetic table: counter-based, entry j depends on (seed, first + j) only
-__global__ void __launch_bounds__(kThreads) k_generate(fq* __restrict__ out, u64 seed, u64 first, size_t n) {
+// synthetic table: counter-based, local entry i is global entry first + i*step and
+// depends on (seed, global index) only -- step = number of shards for a table sharded on its low bits
+__global__ void __launch_bounds__(kThreads) k_generate(fq* __restrict__ out, u64 seed, u64 first, u64 step, size_t n) {
     const size_t stride = (size_t)gridDim.x * kThreads;
     for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride) {
-        u64 j = first + i;
+        u64 j = first + i * step;
         fq x;
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
@@ -494,8 +495,8 @@ void launch_from_le32(const void* in, void* out, size_t n, hipStream_t st) {
 void launch_to_le32(const void* in, void* out, size_t n, hipStream_t st) {
     hipLaunchKernelGGL(k_to_le32, dim3(grid_for(n)), dim3(kThreads), 0, st, (const fq*)in, (fq*)out, n);
 }
-void launch_generate(void* out, uint64_t seed, uint64_t first, size_t n, hipStream_t st) {
-    hipLaunchKernelGGL(k_generate, dim3(grid_for(n)), dim3(kThreads), 0, st, (fq*)out, seed, first, n);
+void launch_generate(void* out, uint64_t seed, uint64_t first, uint64_t step, size_t n, hipStream_t st) {
+    hipLaunchKernelGGL(k_generate, dim3(grid_for(n)), dim3(kThreads), 0, st, (fq*)out, seed, first, step, n);
 }
 void launch_modmul_probe(void* io, int blocks, int iters, hipStream_t st) {
     hipLaunchKernelGGL(k_modmul_probe, dim3(blocks), dim3(kThreads), 0, st, (fq*)io, iters);

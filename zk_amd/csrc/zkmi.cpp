@@ -55,6 +55,7 @@ struct ProfSlot { int kernel; hipEvent_t a, b; uint64_t bytes; };
 struct zk_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    bool own_stream = true;     // false: the caller's stream (zk_ctx_create_on_stream)
     void* partials = nullptr;   // kMaxBlocks * 3 elements
     void* sums_dev = nullptr;   // kSums elements
     uint64_t* sums_host = nullptr; // pinned, kSums elements
@@ -248,7 +249,7 @@ const char* zk_last_error(const zk_ctx* ctx) { return ctx ? ctx->err.c_str() : "
 const char* zk_version(void) { return "zkmi 0.1 (gfx950)"; }
 
 // ---- context --------------------------------------------------------------------------------
-int zk_ctx_create(int device_id, zk_ctx** out) {
+static int ctx_create(int device_id, bool own_stream, hipStream_t stream, zk_ctx** out) {
     if (!out) return ZK_E_ARG;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device_id < 0 || device_id >= ndev) return ZK_E_NO_DEVICE;
@@ -258,6 +259,8 @@ int zk_ctx_create(int device_id, zk_ctx** out) {
     zk_ctx* c = new (std::nothrow) zk_ctx();
     if (!c) return ZK_E_ALLOC;
     c->device = device_id;
+    c->own_stream = own_stream;
+    c->stream = stream;
     int rc = ZK_OK;
     auto fail = [&](hipError_t e, const char* what) {
         if (e == hipSuccess) return false;
@@ -266,7 +269,7 @@ int zk_ctx_create(int device_id, zk_ctx** out) {
         return true;
     };
     if (fail(hipSetDevice(device_id), "hipSetDevice") ||
-        fail(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking), "hipStreamCreate") ||
+        (own_stream && fail(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking), "hipStreamCreate")) ||
         fail(hipMalloc(&c->partials, (size_t)zkk::kMaxBlocks * 3 * kElem), "hipMalloc partials") ||
         fail(hipMalloc(&c->sums_dev, kSums * kElem), "hipMalloc sums") ||
         fail(hipHostMalloc((void**)&c->sums_host, kSums * kElem, hipHostMallocDefault), "hipHostMalloc sums")) {
@@ -276,11 +279,15 @@ int zk_ctx_create(int device_id, zk_ctx** out) {
     *out = c;
     return ZK_OK;
 }
+int zk_ctx_create(int device_id, zk_ctx** out) { return ctx_create(device_id, true, nullptr, out); }
+int zk_ctx_create_on_stream(int device_id, void* hip_stream, zk_ctx** out) {
+    return ctx_create(device_id, false, (hipStream_t)hip_stream, out);
+}
 
 void zk_ctx_destroy(zk_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    (void)hipStreamSynchronize(c->stream);
     for (auto& s : c->prof_pending) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
     for (auto& p : c->prof_free) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     if (c->partials) (void)hipFree(c->partials);
@@ -289,7 +296,7 @@ void zk_ctx_destroy(zk_ctx* c) {
     if (c->work[0]) (void)hipFree(c->work[0]);
     if (c->work[1]) (void)hipFree(c->work[1]);
     if (c->stage) (void)hipFree(c->stage);
-    if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
 void* zk_ctx_stream(zk_ctx* c) { return c ? (void*)c->stream : nullptr; }
@@ -377,13 +384,13 @@ int zk_mle_wrap_device(zk_ctx* c, void* dptr, size_t len, zk_mle** out) {
     return ZK_OK;
 }
 
-int zk_mle_generate(zk_ctx* c, uint64_t seed, uint64_t first, size_t len, zk_mle** out) {
+int zk_mle_generate_strided(zk_ctx* c, uint64_t seed, uint64_t first, uint64_t step, size_t len, zk_mle** out) {
     if (!c || !out) return ZK_E_ARG;
     int rc = set_device(c);
     if (rc) return rc;
     zk_mle* m = nullptr;
     if ((rc = new_mle(c, len, &m))) return rc;
-    zkk::launch_generate(m->d, seed, first, len, c->stream);
+    zkk::launch_generate(m->d, seed, first, step, len, c->stream);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) {
@@ -393,6 +400,21 @@ int zk_mle_generate(zk_ctx* c, uint64_t seed, uint64_t first, size_t len, zk_mle
     }
     *out = m;
     return ZK_OK;
+}
+int zk_mle_generate(zk_ctx* c, uint64_t seed, uint64_t first, size_t len, zk_mle** out) {
+    return zk_mle_generate_strided(c, seed, first, 1, len, out);
+}
+
+// shard `rank` of `world` (a power of two) of a host table: local entry j = global entry j*world + rank
+int zk_mle_upload_mont_shard(zk_ctx* c, const uint64_t* limbs, size_t global_len, int rank, int world, zk_mle** out) {
+    if (!c || !limbs || !out || world <= 0 || rank < 0 || rank >= world || !is_pow2((size_t)world)) return ZK_E_ARG;
+    if (!is_pow2(global_len)) return ZK_E_NOT_POW2;
+    if (global_len < (size_t)world) return ZK_E_ARG;
+    const size_t len = global_len / (size_t)world;
+    std::vector<uint64_t> local;
+    try { local.resize(4 * len); } catch (...) { return ZK_E_ALLOC; }
+    for (size_t j = 0; j < len; ++j) std::memcpy(&local[4 * j], limbs + 4 * (j * (size_t)world + (size_t)rank), kElem);
+    return zk_mle_upload_mont(c, local.data(), len, out);
 }
 
 int zk_mle_clone(const zk_mle* src, zk_mle** out) {
@@ -519,6 +541,129 @@ int zk_mle_round_sums(const zk_mle* m, uint64_t out[8]) {
 }
 
 // ---- sumcheck prover: single MLE ---------------------------------------------------------------
+// Batched rounds (kernels.hip): S = 2^m block sums of the current table; the host runs m rounds
+// on S (half sums of S == half sums of the table, prover.rs:108-116); one device pass then binds
+// those m variables and produces the next batch's block sums.
+//
+// Sharded tables: rank q of `world` holds the entries whose index is q mod world,
+// i.e. a table in the top n-g variables for one assignment q of the g variables bound last.  Sums
+// over index halves add across ranks, so S = sum_q S_q; folds are rank-local.  `sums` is the
+// gathered [world][2^m] array.  folded_out[q] (optional) = rank q's block sums folded at the m
+// challenges: when the local tables are down to 2^m entries these are the entries of the remaining
+// g-variable table, index q.
+namespace {
+void host_rounds(zk_transcript* tr, const uint64_t* sums, int world, unsigned m, uint64_t* coeffs_out, uint64_t* ch_out,
+                 uint64_t* folded_out, uint64_t* total_out) {
+    const unsigned nb = 1u << m;
+    std::vector<Fq> S(nb, zkh::zero()), per(folded_out ? (size_t)world * nb : 0);
+    for (int q = 0; q < world; ++q)
+        for (unsigned b = 0; b < nb; ++b) {
+            const Fq v = zkh::load(sums + 4 * ((size_t)q * nb + b));
+            S[b] = zkh::add(S[b], v);
+            if (folded_out) per[(size_t)q * nb + b] = v;
+        }
+    if (total_out) {
+        Fq total = zkh::zero();
+        for (unsigned b = 0; b < nb; ++b) total = zkh::add(total, S[b]);
+        zkh::store(total_out, total); // evaluation_sum(), prover.rs:170
+    }
+    unsigned slen = nb;
+    for (unsigned t = 0; t < m; ++t) {
+        const unsigned half = slen / 2;
+        Fq e0 = zkh::zero(), e1 = zkh::zero();
+        for (unsigned b = 0; b < half; ++b) { e0 = zkh::add(e0, S[b]); e1 = zkh::add(e1, S[half + b]); }
+        Fq claimed = zkh::add(e0, e1);      // prover.rs:118
+        Fq c1 = zkh::sub(e1, e0);           // interpolate([0,1],[e0,e1]) = [e0, e1-e0], :120-123
+        tr->append_fq(claimed);             // :126-129
+        tr->append_fq(e0);
+        tr->append_fq(c1);
+        Fq r = tr->sample();                // :141-144
+        zkh::store(coeffs_out + 8 * t, e0);
+        zkh::store(coeffs_out + 8 * t + 4, c1);
+        if (ch_out) zkh::store(ch_out + 4 * t, r);
+        for (unsigned b = 0; b < half; ++b) S[b] = zkh::add(S[b], zkh::mul(zkh::sub(S[half + b], S[b]), r)); // evaluation_form.rs:184
+        if (folded_out)
+            for (int q = 0; q < world; ++q) {
+                Fq* P = &per[(size_t)q * nb];
+                for (unsigned b = 0; b < half; ++b) P[b] = zkh::add(P[b], zkh::mul(zkh::sub(P[half + b], P[b]), r));
+            }
+        slen = half;
+    }
+    if (folded_out)
+        for (int q = 0; q < world; ++q) zkh::store(folded_out + 4 * q, per[(size_t)q * nb]);
+}
+} // namespace
+
+struct zk_shard {
+    zk_ctx* ctx;
+    const void* cur; // current local table
+    unsigned ell;    // variables left in it
+    int pass;
+};
+
+int zk_sumcheck_rounds_from_block_sums(zk_transcript* t, const uint64_t* sums, int world, int m, uint64_t* coeffs_out,
+                                       uint64_t* challenges_out, uint64_t* folded_out, uint64_t total_out[4]) {
+    if (!t || !sums || !coeffs_out || world < 1 || m < 1 || m > 30) return ZK_E_ARG;
+    host_rounds(t, sums, world, (unsigned)m, coeffs_out, challenges_out, folded_out, total_out);
+    return ZK_OK;
+}
+
+int zk_shard_begin(zk_ctx* c, const zk_mle* local, zk_shard** out) {
+    if (!c || !local || !out || local->ctx != c) return ZK_E_ARG;
+    zk_shard* s = new (std::nothrow) zk_shard{c, local->d, ilog2(local->len), 0};
+    if (!s) return ZK_E_ALLOC;
+    *out = s;
+    return ZK_OK;
+}
+void zk_shard_end(zk_shard* s) { delete s; }
+int zk_shard_vars_left(const zk_shard* s) { return s ? (int)s->ell : -1; }
+
+// sums_dev_out[b] (b < 2^m) = sum of the b-th contiguous block of the current local table; asynchronous
+int zk_shard_block_sums(zk_shard* s, int m, void* sums_dev_out) {
+    if (!s || !sums_dev_out || m < 1 || m > zkk::kMaxFoldBatch || (unsigned)m > s->ell) return ZK_E_ARG;
+    zk_ctx* c = s->ctx;
+    int rc = set_device(c);
+    if (rc) return rc;
+    const size_t len = (size_t)1 << s->ell;
+    {
+        ProfScope ps(c, ZK_K_BLOCK_SUMS, (uint64_t)len * 32);
+        zkk::launch_block_sums(s->cur, len, m, c->partials, sums_dev_out, c->stream);
+    }
+    HIPCHK(c, hipGetLastError());
+    return ZK_OK;
+}
+
+// bind the top m variables of the current local table at r[0..m) (m successive
+// partially_evaluate((0, r_l)), evaluation_form.rs:163-192) into the context's scratch, and leave the
+// 2^m_next block sums of the result in sums_dev_out; asynchronous.  m_next = 0: no sums (last pass).
+int zk_shard_fold(zk_shard* s, int m, const uint64_t* r_mont, int m_next, void* sums_dev_out) {
+    if (!s || !r_mont || m < 1 || m > zkk::kMaxFoldBatch || (unsigned)m > s->ell) return ZK_E_ARG;
+    if (m_next < 0 || m_next > zkk::kMaxFoldBatch || (unsigned)(m + m_next) > s->ell || (m_next && !sums_dev_out)) return ZK_E_ARG;
+    zk_ctx* c = s->ctx;
+    int rc = set_device(c);
+    if (rc) return rc;
+    const unsigned ell_out = s->ell - (unsigned)m;
+    const size_t lout = (size_t)1 << ell_out;
+    if ((rc = ensure_work(c, s->pass & 1, lout * kElem))) return rc;
+    void* dst = c->work[s->pass & 1];
+    void* sums = m_next ? sums_dev_out : c->sums_dev;
+    {
+        ProfScope ps(c, ZK_K_MULTIFOLD, (uint64_t)(lout << m) * 32 + (uint64_t)lout * 32);
+        if (c->lazy && m >= 2) {
+            uint32_t w28[(1 << zkk::kMaxFoldBatch) * 10];
+            eq_weights28(r_mont, (unsigned)m, w28);
+            zkk::launch_multifold_lazy(m, c->lazy_group, s->cur, dst, lout, w28, m_next, c->partials, sums, c->stream);
+        } else {
+            zkk::launch_multifold(m, s->cur, dst, lout, r_mont, m_next, c->double_buffer, c->partials, sums, c->stream);
+        }
+    }
+    HIPCHK(c, hipGetLastError());
+    s->cur = dst;
+    s->ell = ell_out;
+    ++s->pass;
+    return ZK_OK;
+}
+
 int zk_sumcheck_prove_mle(zk_ctx* c, const zk_mle* poly, int absorb_table, zk_transcript* transcript,
                           uint64_t claim_out[4], uint64_t* coeffs_out, uint64_t* challenges_out) {
     if (!c || !poly || !claim_out) return ZK_E_ARG;
@@ -543,67 +688,21 @@ int zk_sumcheck_prove_mle(zk_ctx* c, const zk_mle* poly, int absorb_table, zk_tr
         return ZK_OK;
     }
 
-    // Batched rounds (kernels.hip): S = 2^m block sums of the current table; the host runs m rounds
-    // on S (half sums of S == half sums of the table, prover.rs:108-116); one device pass then binds
-    // those m variables and produces the next batch's block sums.
     const unsigned M = (unsigned)c->fold_batch;
-    unsigned ell = n;                       // variables left in the device table
-    unsigned m = std::min(M, ell);
-    Fq S[kSums];
-    {
-        ProfScope ps(c, ZK_K_BLOCK_SUMS, (uint64_t)len * 32);
-        zkk::launch_block_sums(poly->d, len, (int)m, c->partials, c->sums_dev, c->stream);
-    }
-    if ((rc = fetch_block_sums(c, 1 << m, S))) return rc;
-    {
-        Fq total = zkh::zero();
-        for (unsigned b = 0; b < (1u << m); ++b) total = zkh::add(total, S[b]);
-        zkh::store(claim_out, total); // evaluation_sum(), prover.rs:170
-    }
-
-    const void* cur = poly->d;
-    unsigned k = 0; // round index
-    int pass = 0;
+    zk_shard st{c, poly->d, n, 0};
+    unsigned m = std::min(M, st.ell), k = 0;
+    if ((rc = zk_shard_block_sums(&st, (int)m, c->sums_dev))) return rc;
     for (;;) {
+        HIPCHK(c, hipMemcpyAsync(c->sums_host, c->sums_dev, ((size_t)kElem) << m, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
         uint64_t rs[4 * zkk::kMaxFoldBatch];
-        unsigned slen = 1u << m;
-        for (unsigned t = 0; t < m; ++t, ++k) {
-            const unsigned half = slen / 2;
-            Fq e0 = zkh::zero(), e1 = zkh::zero();
-            for (unsigned b = 0; b < half; ++b) { e0 = zkh::add(e0, S[b]); e1 = zkh::add(e1, S[half + b]); }
-            Fq claimed = zkh::add(e0, e1);      // prover.rs:118
-            Fq c1 = zkh::sub(e1, e0);           // interpolate([0,1],[e0,e1]) = [e0, e1-e0], :120-123
-            tr->append_fq(claimed);             // :126-129
-            tr->append_fq(e0);
-            tr->append_fq(c1);
-            Fq r = tr->sample();                // :141-144
-            zkh::store(coeffs_out + 8 * k, e0);
-            zkh::store(coeffs_out + 8 * k + 4, c1);
-            if (challenges_out) zkh::store(challenges_out + 4 * k, r);
-            zkh::store(rs + 4 * t, r);
-            for (unsigned b = 0; b < half; ++b) S[b] = zkh::add(S[b], zkh::mul(zkh::sub(S[half + b], S[b]), r)); // evaluation_form.rs:184
-            slen = half;
-        }
-        ell -= m;
-        if (ell == 0) break; // the fully folded table (one entry) is never used by the prover
-        const unsigned m_next = std::min(M, ell);
-        const size_t lout = (size_t)1 << ell;
-        if ((rc = ensure_work(c, pass & 1, lout * kElem))) return rc;
-        void* dst = c->work[pass & 1];
-        {
-            ProfScope ps(c, ZK_K_MULTIFOLD, (uint64_t)(lout << m) * 32 + (uint64_t)lout * 32);
-            if (c->lazy && m >= 2) {
-                uint32_t w28[(1 << zkk::kMaxFoldBatch) * 10];
-                eq_weights28(rs, m, w28);
-                zkk::launch_multifold_lazy((int)m, c->lazy_group, cur, dst, lout, w28, (int)m_next, c->partials, c->sums_dev, c->stream);
-            } else {
-                zkk::launch_multifold((int)m, cur, dst, lout, rs, (int)m_next, c->double_buffer, c->partials, c->sums_dev, c->stream);
-            }
-        }
-        if ((rc = fetch_block_sums(c, 1 << m_next, S))) return rc;
-        cur = dst;
+        host_rounds(tr, c->sums_host, 1, m, coeffs_out + 8 * k, rs, nullptr, k == 0 ? claim_out : nullptr);
+        if (challenges_out) std::memcpy(challenges_out + 4 * k, rs, (size_t)m * kElem);
+        k += m;
+        if (st.ell == m) break; // the fully folded table (one entry) is never used by the prover
+        const unsigned m_next = std::min(M, st.ell - m);
+        if ((rc = zk_shard_fold(&st, (int)m, rs, (int)m_next, c->sums_dev))) return rc;
         m = m_next;
-        ++pass;
     }
     prof_collect(c);
     return ZK_OK;
@@ -739,6 +838,12 @@ int zk_prof_enable(zk_ctx* c, int on) {
     c->prof_on = on != 0;
     return ZK_OK;
 }
+int zk_prof_collect(zk_ctx* c) { // accounts the launches recorded since the last collect; synchronizes the stream
+    if (!c) return ZK_E_ARG;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    prof_collect(c);
+    return ZK_OK;
+}
 int zk_prof_reset(zk_ctx* c) {
     if (!c) return ZK_E_ARG;
     for (int k = 0; k < ZK_K_COUNT; ++k) { c->prof_launches[k] = 0; c->prof_ms[k] = 0; c->prof_bytes[k] = 0; }
@@ -757,7 +862,7 @@ int zk_bench_modmul(zk_ctx* c, int blocks, int iters, double* ms_out) {
     if (rc) return rc;
     void* buf = nullptr;
     HIPCHK(c, hipMalloc(&buf, (size_t)blocks * 256 * kElem));
-    zkk::launch_generate(buf, 42, 0, (size_t)blocks * 256, c->stream);
+    zkk::launch_generate(buf, 42, 0, 1, (size_t)blocks * 256, c->stream);
     hipEvent_t a, b;
     HIPCHK(c, hipEventCreate(&a));
     HIPCHK(c, hipEventCreate(&b));

@@ -48,11 +48,20 @@ class MultiLinearPolynomial:
         return cls(ctx=ctx, _handle=h)
 
     @classmethod
-    def generate(cls, seed: int, length: int, first: int = 0, ctx: Context | None = None):
-        """Synthetic table made on the device."""
+    def generate(cls, seed: int, length: int, first: int = 0, ctx: Context | None = None, step: int = 1):
+        """Synthetic table made on the device; local entry j = global entry first + j*step."""
         ctx = ctx or default_context()
         h = C.c_void_p()
-        check(lib().zk_mle_generate(ctx.h, seed, first, length, C.byref(h)), ctx.h)
+        check(lib().zk_mle_generate_strided(ctx.h, seed, first, step, length, C.byref(h)), ctx.h)
+        return cls(ctx=ctx, _handle=h)
+
+    @classmethod
+    def upload_shard(cls, evaluation_points, rank: int, world: int, ctx: Context | None = None):
+        """Shard `rank` of `world` of a host table: local entry j = global entry j*world + rank."""
+        ctx = ctx or default_context()
+        pts = _limbs(evaluation_points).reshape(-1, 4)
+        h = C.c_void_p()
+        check(lib().zk_mle_upload_mont_shard(ctx.h, pts.ctypes.data_as(u64p), pts.shape[0], rank, world, C.byref(h)), ctx.h)
         return cls(ctx=ctx, _handle=h)
 
     @classmethod

@@ -1,0 +1,184 @@
+"""Single-MLE sumcheck prover over a table sharded across the GPUs of one node.
+
+One process per GPU.  Rank q of `world` (a power of two, g = log2 world) holds the entries whose
+global index is q mod world, stored at index >> g: the table is sharded on the g variables that are
+bound LAST, so for the first n-g rounds every fold pair (j, j + N/2) of evaluation_form.rs:61-79
+lives on one GPU and the folds are rank-local.  The only exchange is the per-pass all-gather of the
+2^m block sums of every rank (<= 512 B per rank; RCCL over xGMI through torch.distributed, backend
+"nccl"); every rank then runs the identical host part (Keccak transcript, round polynomials,
+challenges), so nothing is broadcast back.  When the local tables are used up, the remaining
+g-variable table (one entry per rank) is already on every host -- it is each rank's block sums
+folded at the last challenges -- and the last g rounds run on the host.
+
+The loop is written against a small "shard" interface (vars_left / new_sums / block_sums / fold) so
+the multi-rank logic can be exercised on CPU ranks (gloo) in tests with a stand-in shard; the product
+shard is DeviceShard = zk_shard_* of libzkmi.so.  There is no CPU compute path in this package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from ._lib import check, lib, u64p
+from .context import Context
+from .polynomials import MultiLinearPolynomial
+from .transcript import Transcript
+
+MAX_FOLD_BATCH = 4
+
+
+def _ptr(a: np.ndarray):
+    return a.ctypes.data_as(u64p)
+
+
+def rounds_from_block_sums(transcript: Transcript, sums: np.ndarray, want_folded: bool = False, want_total: bool = False):
+    """Host part of one batch of m rounds (zk_sumcheck_rounds_from_block_sums; no GPU needed).
+    sums: (world, 2^m, 4) uint64.  -> (coeffs (m,2,4), challenges (m,4), folded (world,4) | None, total (4,) | None)"""
+    sums = np.ascontiguousarray(sums, dtype=np.uint64)
+    world, nb = sums.shape[0], sums.shape[1]
+    m = nb.bit_length() - 1
+    if nb != 1 << m or m < 1:
+        raise ValueError("block-sum count must be a power of two >= 2")
+    coeffs = np.empty((m, 2, 4), dtype=np.uint64)
+    ch = np.empty((m, 4), dtype=np.uint64)
+    folded = np.empty((world, 4), dtype=np.uint64) if want_folded else None
+    total = np.empty(4, dtype=np.uint64) if want_total else None
+    check(lib().zk_sumcheck_rounds_from_block_sums(
+        transcript.h, _ptr(sums), world, m, _ptr(coeffs), _ptr(ch),
+        _ptr(folded) if want_folded else None, _ptr(total) if want_total else None))
+    return coeffs, ch, folded, total
+
+
+class DeviceShard:
+    """This rank's local table on its GPU (zk_shard in include/zkmi.h).  Sums land in torch device
+    tensors so the collective can take them without a host round trip."""
+
+    def __init__(self, local: MultiLinearPolynomial):
+        import torch
+
+        self._torch = torch
+        self.local = local
+        self.ctx = local.ctx
+        h = C.c_void_p()
+        check(lib().zk_shard_begin(self.ctx.h, local.h, C.byref(h)), self.ctx.h)
+        self.h = h
+
+    def vars_left(self) -> int:
+        return lib().zk_shard_vars_left(self.h)
+
+    def new_sums(self, count: int):
+        return self._torch.empty((count, 4), dtype=self._torch.int64, device=self._torch.device("cuda", self.ctx.device_id))
+
+    def block_sums(self, m: int, out) -> None:
+        check(lib().zk_shard_block_sums(self.h, m, C.c_void_p(out.data_ptr())), self.ctx.h)
+
+    def fold(self, m: int, r: np.ndarray, m_next: int, out) -> None:
+        r = np.ascontiguousarray(r, dtype=np.uint64)
+        check(lib().zk_shard_fold(self.h, m, _ptr(r), m_next, C.c_void_p(out.data_ptr())), self.ctx.h)
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().zk_shard_end(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def gather_sums(local, world: int, dist=None, group=None) -> np.ndarray:
+    """all-gather of one (k,4) int64 tensor per rank -> (world, k, 4) uint64 on the host.
+    nccl: the collective runs on the device tensors (RCCL), one D2H of the gathered block;
+    other backends (gloo in tests): D2H first, collective on host tensors."""
+    import torch
+
+    if world == 1 or dist is None:
+        return local.cpu().numpy().view(np.uint64)[None]
+    if dist.get_backend(group) == "nccl":
+        out = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(out, local.contiguous(), group=group)
+        return out.cpu().numpy().view(np.uint64)
+    host = local.cpu().contiguous()
+    parts = [torch.empty_like(host) for _ in range(world)]
+    dist.all_gather(parts, host, group=group)
+    return torch.stack(parts).numpy().view(np.uint64)
+
+
+def generate_round_polys_sharded(shard, transcript: Transcript, world: int, dist=None, group=None,
+                                 fold_batch: int = MAX_FOLD_BATCH):
+    """generate_round_polys (sumcheck/src/prover.rs:45-155, MLE branch) for a sharded table.
+    Every rank returns the same (claim (4,), round_polys (n,2,4), challenges (n,4))."""
+    g = world.bit_length() - 1
+    if world != 1 << g:
+        raise ValueError("world size must be a power of two")
+    ell = shard.vars_left()
+    if ell < 1:
+        raise ValueError("each rank needs at least 2 local entries")
+    n = ell + g
+    M = max(1, min(fold_batch, MAX_FOLD_BATCH))
+    coeffs = np.empty((n, 2, 4), dtype=np.uint64)
+    ch = np.empty((n, 4), dtype=np.uint64)
+    claim = None
+    buf = shard.new_sums(1 << M)
+    m, k = min(M, ell), 0
+    shard.block_sums(m, buf)
+    while True:
+        sums = gather_sums(buf[: 1 << m], world, dist, group)
+        last = ell == m
+        c, r, folded, total = rounds_from_block_sums(transcript, sums, want_folded=last, want_total=k == 0)
+        coeffs[k:k + m], ch[k:k + m] = c, r
+        if k == 0:
+            claim = total
+        k += m
+        if last:
+            break
+        m_next = min(M, ell - m)
+        shard.fold(m, r, m_next, buf)
+        ell -= m
+        m = m_next
+    if g:  # the remaining g-variable table, entry q = rank q's fully folded local table
+        c, r, _, _ = rounds_from_block_sums(transcript, folded.reshape(1, world, 4))
+        coeffs[k:], ch[k:] = c, r
+    return claim, coeffs, ch
+
+
+def absorb_table_sharded(local: MultiLinearPolynomial, transcript: Transcript, world: int, dist=None, group=None,
+                         chunk: int = 1 << 16) -> None:
+    """transcript.append(&init_polynomial.to_bytes()) (prover.rs:162) for a sharded table: the byte
+    stream is in GLOBAL index order, so chunks of every shard are gathered and interleaved.  Serial
+    Keccak over 32*N bytes on every rank -- meant for parity tests, not for speed."""
+    import torch
+
+    n_local = len(local)
+    base = lib().zk_mle_device_ptr(local.h)
+    for off in range(0, n_local, chunk):
+        cnt = min(chunk, n_local - off)
+        if cnt & (cnt - 1):
+            raise ValueError("chunk and local length must be powers of two")
+        part = MultiLinearPolynomial.wrap_device(base + 32 * off, cnt, ctx=local.ctx)
+        mine = torch.from_numpy(np.frombuffer(part.to_bytes(), dtype=np.uint8).reshape(cnt, 32).copy())
+        if world == 1 or dist is None:
+            allp = mine[None]
+        else:
+            if dist.get_backend(group) == "nccl":
+                dev = mine.to(torch.device("cuda", local.ctx.device_id))
+                outd = torch.empty((world, cnt, 32), dtype=torch.uint8, device=dev.device)
+                dist.all_gather_into_tensor(outd, dev, group=group)
+                allp = outd.cpu()
+            else:
+                parts = [torch.empty_like(mine) for _ in range(world)]
+                dist.all_gather(parts, mine, group=group)
+                allp = torch.stack(parts)
+        transcript.append(allp.permute(1, 0, 2).contiguous().numpy().tobytes())
+
+
+def torch_stream_context(local_rank: int) -> Context:
+    """A context whose kernels run on torch's current stream of cuda:local_rank, so that they order
+    with torch.distributed's collectives without extra synchronisation."""
+    import torch
+
+    torch.cuda.set_device(local_rank)
+    return Context.on_stream(local_rank, torch.cuda.current_stream().cuda_stream)
