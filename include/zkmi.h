@@ -154,6 +154,44 @@ int zk_sumcheck_partial_verify(const uint64_t claim_mont[4], const uint64_t *coe
 int zk_sumcheck_verify_mle(zk_ctx *ctx, const zk_mle *poly, const uint64_t claim_mont[4], const uint64_t *coeffs,
                            size_t n_rounds, int *ok_out);
 
+/* ---- MultiLinearPolynomial helpers the GKR prover uses (evaluation_form.rs) -------------- */
+int zk_mle_w_add(const zk_mle *w_b, const zk_mle *w_c, zk_mle **out);       /* w_add :303-308 via operate_w :82-112: out[i] = w_b[i / L] + w_c[i % L] */
+int zk_mle_w_mul(const zk_mle *self, const zk_mle *other, zk_mle **out);    /* w_mul(&self, other) :310-312 = operate_w(other, self): out[i] = other[i / L] * self[i % L] */
+int zk_mle_scalar_mul(const zk_mle *m, const uint64_t s_mont[4], zk_mle **out); /* scalar_mul :151-153 */
+int zk_mle_add(const zk_mle *a, const zk_mle *b, zk_mle **out);             /* _add / Add :241-258 */
+
+/* ---- arithmetic_circuit::Circuit (arithmetic_circuit/src/circuit.rs) ---------------------- */
+typedef struct zk_circuit zk_circuit;
+/* Circuit::new :15-20.  gates: for every layer (layers[0] is next to the inputs) its gates in order,
+ * each as three u64 (left, right, op) with op 0 = Add, 1 = Mul (gate.rs:7-22); layer_len[i] = gates in layer i.
+ * The wiring is kept as gate lists + per-layer CSR indices on the device (never as dense tables). */
+int zk_circuit_create(zk_ctx *ctx, const uint64_t *gates, const size_t *layer_len, size_t n_layers, zk_circuit **out);
+void zk_circuit_free(zk_circuit *c);
+size_t zk_circuit_layer_count(const zk_circuit *c);                         /* get_layer_count :149-151 */
+/* proof shape: output_len = len(W_0); rounds_per_layer[i] (i counted from the OUTPUT layer, n_layers
+ * entries) = 2*k_in of that layer = rounds of its sumcheck */
+int zk_circuit_shape(const zk_circuit *c, size_t *output_len, size_t *rounds_per_layer);
+/* evaluate_at_input :37-59 -> n_layers+1 new tables, layers_out[0] = the inputs, widths padded as :43 */
+int zk_circuit_evaluate(zk_circuit *c, const zk_mle *inputs, zk_mle **layers_out);
+/* get_add_i (op 0) / get_mul_i (op 1) :82-146 as the reference's DENSE 2^(k_out+2k_in) table; layer_idx
+ * counts from the output.  For small circuits and parity tests: the prover below never builds it. */
+int zk_circuit_gate_poly(zk_circuit *c, size_t layer_idx, int op, zk_mle **out);
+
+/* ---- GKRProver::generate_proof (gkr/src/prover.rs:24-154) --------------------------------- */
+/* GKRProof (gkr_protocol.rs:8-26) comes back as
+ *   output_poly_out  output_len elements            (GKRProof.output_poly = W_0)
+ *   w_evals_out      (n_layers-1) x 2 elements      (w_polys_evals: (W_i(r_b), W_i(r_c)), layers 1..)
+ *   claims_out       n_layers elements              (sumcheck_proofs[i].initial_claim_sum)
+ *   coeffs_out       sum_i rounds_per_layer[i] x 3  (sumcheck_proofs[i].round_polys, layer after layer)
+ *   layer_ms_out     optional, n_layers + 2: device time per layer (HIP events), then the host wall time of
+ *                    the circuit evaluation and of the serial Keccak absorb of W_0 (prover.rs:46)
+ * Per layer the add_i/mul_i predicates folded at the previous challenges (utils.rs:16-65) are built
+ * on the device from the gate list, never as dense tables; round polynomials are identical field
+ * elements.  Needs 2^k_in == len(W_{i+1}) on every layer (the reference panics otherwise). */
+int zk_gkr_prove(zk_ctx *ctx, zk_circuit *circuit, zk_transcript *transcript, const zk_mle *inputs,
+                 uint64_t *output_poly_out, uint64_t *w_evals_out, uint64_t *claims_out, uint64_t *coeffs_out,
+                 double *layer_ms_out);
+
 /* ---- tuning / measurement hooks (no reference counterpart) ---------------------------- */
 /* Rounds bound per device pass by the single-MLE prover (1..4, default 4) and the fold kernel
  * variant: 0 = inner product with eq weights, one reduction per output (default); 1 = fold tree;

@@ -5,12 +5,14 @@ Host-side mirror of the reference's prover API over the C ABI of libzkmi.so
 calls raise.
 """
 from ._lib import LIB_PATH, SYMBOLS, ZkError, lib
+from .circuit import Circuit, Gate, Operation
 from .context import Context, default_context
+from .gkr import GKRProof, GKRProver
 from .polynomials import MultiLinearPolynomial, ProductPolynomial, SumPolynomial
 from .sumcheck import SumCheckProof, SumcheckProver, SumcheckVerifier
 from .transcript import Transcript
 
 __all__ = [
     "LIB_PATH", "SYMBOLS", "ZkError", "lib", "Context", "default_context", "MultiLinearPolynomial",
-    "ProductPolynomial", "SumPolynomial", "SumCheckProof", "SumcheckProver", "SumcheckVerifier", "Transcript",
+    "ProductPolynomial", "SumPolynomial", "Circuit", "Gate", "Operation", "GKRProof", "GKRProver", "SumCheckProof", "SumcheckProver", "SumcheckVerifier", "Transcript",
 ]

@@ -64,6 +64,17 @@ SYMBOLS = [
     ("zk_shard_fold", C.c_int, [_VP, C.c_int, u64p, C.c_int, _VP]),
     ("zk_sumcheck_partial_verify", C.c_int, [u64p, u64p, C.c_size_t, C.c_size_t, _VP, C.POINTER(C.c_int), u64p, u64p]),
     ("zk_sumcheck_verify_mle", C.c_int, [_VP, _VP, u64p, u64p, C.c_size_t, C.POINTER(C.c_int)]),
+    ("zk_mle_w_add", C.c_int, [_VP, _VP, C.POINTER(_VP)]),
+    ("zk_mle_w_mul", C.c_int, [_VP, _VP, C.POINTER(_VP)]),
+    ("zk_mle_scalar_mul", C.c_int, [_VP, u64p, C.POINTER(_VP)]),
+    ("zk_mle_add", C.c_int, [_VP, _VP, C.POINTER(_VP)]),
+    ("zk_circuit_create", C.c_int, [_VP, u64p, C.POINTER(C.c_size_t), C.c_size_t, C.POINTER(_VP)]),
+    ("zk_circuit_free", None, [_VP]),
+    ("zk_circuit_layer_count", C.c_size_t, [_VP]),
+    ("zk_circuit_shape", C.c_int, [_VP, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    ("zk_circuit_evaluate", C.c_int, [_VP, _VP, C.POINTER(_VP)]),
+    ("zk_circuit_gate_poly", C.c_int, [_VP, C.c_size_t, C.c_int, C.POINTER(_VP)]),
+    ("zk_gkr_prove", C.c_int, [_VP, _VP, _VP, _VP, u64p, u64p, u64p, u64p, C.POINTER(C.c_double)]),
     ("zk_ctx_set_fold_batch", C.c_int, [_VP, C.c_int, C.c_int]),
     ("zk_prof_enable", C.c_int, [_VP, C.c_int]),
     ("zk_prof_reset", C.c_int, [_VP]),

@@ -1,0 +1,379 @@
+// gkr.cpp -- arithmetic_circuit::Circuit and GKRProver::generate_proof on the device
+// (arithmetic_circuit/src/circuit.rs:14-152, gkr/src/prover.rs:24-154, gkr/src/utils.rs:5-65).
+//
+// The circuit keeps its wiring as gate lists plus two CSR indices per layer (gates grouped by left
+// and by right input), built once on the host.  A layer's sumcheck over the 2 k_in variables (b, c)
+// of  f(b,c) = mul'(b,c) W(b) W(c) + add'(b,c) (W(b) + W(c))  runs as two degree-2 sumchecks over
+// 2^k_in-entry tables on the SAME transcript (gkr_kernels.hip explains why the round polynomials are
+// the field elements the reference's dense computation produces):
+//   rounds over b:  Sum[ Prod[A, W], Prod[H2, 1] ]              A, H2 from k_gkr_phase1
+//   rounds over c:  Sum[ Prod[W(u) M, W], Prod[Ad, W(u) + W] ]  M, Ad from k_gkr_phase2 (u = the b-challenges)
+// Both use the degree-2 prover of zkmi.cpp unchanged.  W(u) and W(v) fall out of the last folds and
+// are the next layer's W(r_b), W(r_c) (prover.rs:87-99).
+#include <chrono>
+
+#include "gkr_kernels.h"
+#include "zkmi_internal.hpp"
+
+namespace {
+
+struct LayerDev {
+    size_t n_gates = 0, n_out = 0; // n_out = max(next_pow2(n_gates), 2), circuit.rs:43, :89-94
+    int k_out = 0, k_in = 0;       // k_in = log2(next_pow2(max index + 1)), circuit.rs:96-109
+    size_t max_index = 0;
+    uint32_t *left = nullptr, *right = nullptr, *lptr = nullptr, *lidx = nullptr, *rptr = nullptr, *ridx = nullptr;
+    uint8_t* op = nullptr;
+    std::vector<uint32_t> h_left, h_right; // host copies (dense gate polys, checks)
+    std::vector<uint8_t> h_op;
+};
+
+size_t next_pow2(size_t n) {
+    size_t p = 1;
+    while (p < n) p <<= 1;
+    return p;
+}
+
+template <class T>
+int to_device(zk_ctx* c, T** dst, const std::vector<T>& src) {
+    const size_t bytes = std::max<size_t>(src.size(), 1) * sizeof(T);
+    HIPCHK(c, hipMalloc((void**)dst, bytes));
+    if (!src.empty()) HIPCHK(c, hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+    return ZK_OK;
+}
+
+// counting sort of gate ids by key (< n_keys) -> CSR
+void build_csr(const std::vector<uint32_t>& key, size_t n_keys, std::vector<uint32_t>& ptr, std::vector<uint32_t>& idx) {
+    ptr.assign(n_keys + 1, 0);
+    for (uint32_t k : key) ++ptr[k + 1];
+    for (size_t i = 0; i < n_keys; ++i) ptr[i + 1] += ptr[i];
+    idx.resize(key.size());
+    std::vector<uint32_t> fill(ptr.begin(), ptr.end() - 1);
+    for (uint32_t g = 0; g < key.size(); ++g) idx[fill[key[g]]++] = g;
+}
+
+} // namespace
+
+struct zk_circuit {
+    zk_ctx* ctx;
+    int device;
+    std::vector<LayerDev> layers; // layers[0] is next to the inputs (circuit.rs:11)
+};
+
+namespace {
+
+// eq(x, .) * scale over k variables into `out` (2^k entries); hi/lo: scratch of >= 2^ceil(k/2) entries each
+void build_eq(zk_ctx* c, void* out, int k, const uint64_t* x, const Fq& scale, void* hi, void* lo) {
+    const int k_lo = k / 2, k_hi = k - k_lo;
+    const Fq one = zkh::one();
+    zkk::launch_eq_small(hi, k_hi, x, scale.l, c->stream);
+    zkk::launch_eq_small(lo, k_lo, x + 4 * k_hi, one.l, c->stream);
+    zkk::launch_eq_outer(out, (size_t)1 << k, k_lo, hi, lo, nullptr, nullptr, c->stream);
+}
+// alpha * eq(xa, .) + beta * eq(xb, .)
+void build_eq2(zk_ctx* c, void* out, int k, const uint64_t* xa, const Fq& alpha, const uint64_t* xb, const Fq& beta, void* scratch4[4]) {
+    const int k_lo = k / 2, k_hi = k - k_lo;
+    const Fq one = zkh::one();
+    zkk::launch_eq_small(scratch4[0], k_hi, xa, alpha.l, c->stream);
+    zkk::launch_eq_small(scratch4[1], k_lo, xa + 4 * k_hi, one.l, c->stream);
+    zkk::launch_eq_small(scratch4[2], k_hi, xb, beta.l, c->stream);
+    zkk::launch_eq_small(scratch4[3], k_lo, xb + 4 * k_hi, one.l, c->stream);
+    zkk::launch_eq_outer(out, (size_t)1 << k, k_lo, scratch4[0], scratch4[1], scratch4[2], scratch4[3], c->stream);
+}
+
+struct DevBuf { // hipFree on scope exit
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+};
+
+} // namespace
+
+extern "C" {
+
+int zk_circuit_create(zk_ctx* c, const uint64_t* gates, const size_t* layer_len, size_t n_layers, zk_circuit** out) {
+    if (!c || !out || (n_layers && (!gates || !layer_len))) return ZK_E_ARG;
+    int rc = set_device(c);
+    if (rc) return rc;
+    zk_circuit* ci = new (std::nothrow) zk_circuit{c, c->device, {}};
+    if (!ci) return ZK_E_ALLOC;
+    ci->layers.resize(n_layers);
+    size_t off = 0;
+    for (size_t i = 0; i < n_layers; ++i) {
+        LayerDev& L = ci->layers[i];
+        L.n_gates = layer_len[i];
+        if (L.n_gates == 0 || L.n_gates > ((size_t)1 << 30)) { zk_circuit_free(ci); return ZK_E_ARG; } // `.max().unwrap()` on no gates panics, circuit.rs:104-107
+        L.n_out = std::max<size_t>(next_pow2(L.n_gates), 2);
+        L.k_out = (int)ilog2(L.n_out);
+        L.h_left.resize(L.n_gates);
+        L.h_right.resize(L.n_gates);
+        L.h_op.resize(L.n_gates);
+        size_t mx = 0;
+        for (size_t g = 0; g < L.n_gates; ++g, ++off) {
+            const uint64_t l = gates[3 * off], r = gates[3 * off + 1], o = gates[3 * off + 2];
+            if (l >= ((uint64_t)1 << 31) || r >= ((uint64_t)1 << 31) || o > 1) { zk_circuit_free(ci); return ZK_E_ARG; }
+            L.h_left[g] = (uint32_t)l;
+            L.h_right[g] = (uint32_t)r;
+            L.h_op[g] = (uint8_t)o;
+            mx = std::max<size_t>(mx, std::max<size_t>(l, r));
+        }
+        L.max_index = mx;
+        L.k_in = (int)ilog2(next_pow2(mx + 1));
+        if (L.k_in > 2 * zkk::kMaxEqVars || L.k_out > 2 * zkk::kMaxEqVars) { zk_circuit_free(ci); return ZK_E_ARG; }
+        std::vector<uint32_t> lptr, lidx, rptr, ridx;
+        build_csr(L.h_left, (size_t)1 << L.k_in, lptr, lidx);
+        build_csr(L.h_right, (size_t)1 << L.k_in, rptr, ridx);
+        if ((rc = to_device(c, &L.left, L.h_left)) || (rc = to_device(c, &L.right, L.h_right)) || (rc = to_device(c, &L.op, L.h_op)) ||
+            (rc = to_device(c, &L.lptr, lptr)) || (rc = to_device(c, &L.lidx, lidx)) || (rc = to_device(c, &L.rptr, rptr)) ||
+            (rc = to_device(c, &L.ridx, ridx))) {
+            zk_circuit_free(ci);
+            return rc;
+        }
+    }
+    *out = ci;
+    return ZK_OK;
+}
+
+void zk_circuit_free(zk_circuit* ci) {
+    if (!ci) return;
+    (void)hipSetDevice(ci->device);
+    for (auto& L : ci->layers)
+        for (void* p : {(void*)L.left, (void*)L.right, (void*)L.op, (void*)L.lptr, (void*)L.lidx, (void*)L.rptr, (void*)L.ridx})
+            if (p) (void)hipFree(p);
+    delete ci;
+}
+
+size_t zk_circuit_layer_count(const zk_circuit* ci) { return ci ? ci->layers.size() : 0; } // get_layer_count, circuit.rs:149-151
+
+int zk_circuit_shape(const zk_circuit* ci, size_t* output_len, size_t* rounds_per_layer) {
+    if (!ci || ci->layers.empty()) return ZK_E_ARG;
+    const size_t L = ci->layers.size();
+    if (output_len) *output_len = ci->layers[L - 1].n_out;
+    if (rounds_per_layer)
+        for (size_t i = 0; i < L; ++i) rounds_per_layer[i] = 2 * (size_t)ci->layers[L - 1 - i].k_in;
+    return ZK_OK;
+}
+
+// evaluate_at_input (circuit.rs:37-59): layers_out[0] = the inputs, layers_out[i+1] = outputs of layers[i]
+int zk_circuit_evaluate(zk_circuit* ci, const zk_mle* inputs, zk_mle** layers_out) {
+    if (!ci || !inputs || !layers_out || inputs->ctx != ci->ctx) return ZK_E_ARG;
+    zk_ctx* c = ci->ctx;
+    int rc = set_device(c);
+    if (rc) return rc;
+    const size_t L = ci->layers.size();
+    for (size_t i = 0; i <= L; ++i) layers_out[i] = nullptr;
+    auto fail = [&](int code) {
+        for (size_t i = 0; i <= L; ++i) { zk_mle_free(layers_out[i]); layers_out[i] = nullptr; }
+        return code;
+    };
+    if ((rc = zk_mle_clone(inputs, &layers_out[0]))) return rc;
+    for (size_t i = 0; i < L; ++i) {
+        const LayerDev& Ly = ci->layers[i];
+        if (Ly.max_index >= layers_out[i]->len) return fail(ZK_E_ARG); // running_inputs[gate.left] out of bounds panics, circuit.rs:47-48
+        if ((rc = new_mle(c, Ly.n_out, &layers_out[i + 1]))) return fail(rc);
+        zkk::launch_circuit_layer(layers_out[i]->d, layers_out[i + 1]->d, Ly.left, Ly.right, Ly.op, Ly.n_gates, Ly.n_out, c->stream);
+    }
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) {
+        c->err = std::string("circuit evaluate: ") + hipGetErrorString(e);
+        return fail(ZK_E_HIP);
+    }
+    return ZK_OK;
+}
+
+// get_add_i / get_mul_i (circuit.rs:82-146), DENSE: 2^(k_out + 2 k_in) entries -- small circuits only
+int zk_circuit_gate_poly(zk_circuit* ci, size_t layer_idx, int op, zk_mle** out) {
+    if (!ci || !out || (op != 0 && op != 1)) return ZK_E_ARG;
+    if (layer_idx >= ci->layers.size()) return ZK_E_LAYER_OOB; // circuit.rs:83-85
+    zk_ctx* c = ci->ctx;
+    int rc = set_device(c);
+    if (rc) return rc;
+    const LayerDev& Ly = ci->layers[ci->layers.size() - layer_idx - 1];
+    const int bits = Ly.k_out + 2 * Ly.k_in;
+    if (bits > 34) return ZK_E_ALLOC; // 2^34 x 32 B = 512 GiB: the dense table does not exist at this size
+    zk_mle* m = nullptr;
+    if ((rc = new_mle(c, (size_t)1 << bits, &m))) return rc;
+    zkk::launch_gate_poly(m->d, m->len, Ly.left, Ly.right, Ly.op, Ly.n_gates, Ly.k_in, op, c->stream);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) {
+        c->err = std::string("gate poly: ") + hipGetErrorString(e);
+        zk_mle_free(m);
+        return ZK_E_HIP;
+    }
+    *out = m;
+    return ZK_OK;
+}
+
+// ---- elementwise MultiLinearPolynomial helpers the GKR prover uses (evaluation_form.rs) ----------
+static int finish_new(zk_ctx* c, zk_mle* m, zk_mle** out, const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) {
+        c->err = std::string(what) + ": " + hipGetErrorString(e);
+        zk_mle_free(m);
+        return ZK_E_HIP;
+    }
+    *out = m;
+    return ZK_OK;
+}
+static int w_op(const zk_mle* wb, const zk_mle* wc, int mul, zk_mle** out) {
+    if (!wb || !wc || !out || wb->ctx != wc->ctx) return ZK_E_ARG;
+    // operate_w indexes w_b by i / w_b.len and w_c by i % w_c.len over w_b.len * w_c.len entries: only
+    // meaningful (and only used) with equal lengths; unequal lengths index out of bounds in the reference
+    if (wb->len != wc->len) return ZK_E_LEN_MISMATCH;
+    zk_ctx* c = wb->ctx;
+    int rc = set_device(c);
+    if (rc) return rc;
+    zk_mle* m = nullptr;
+    if ((rc = new_mle(c, wb->len * wc->len, &m))) return rc;
+    zkk::launch_w_op(m->d, wb->d, wc->d, wb->len, mul, c->stream);
+    return finish_new(c, m, out, "w_add/w_mul");
+}
+int zk_mle_w_add(const zk_mle* wb, const zk_mle* wc, zk_mle** out) { return w_op(wb, wc, 0, out); } // w_add :303-308
+// w_mul(&self, other) = operate_w(other, self, Mul) (:310-312): `other` supplies the HIGH index bits
+int zk_mle_w_mul(const zk_mle* self, const zk_mle* other, zk_mle** out) { return w_op(other, self, 1, out); }
+int zk_mle_scalar_mul(const zk_mle* m, const uint64_t s[4], zk_mle** out) { // :151-153
+    if (!m || !s || !out) return ZK_E_ARG;
+    zk_ctx* c = m->ctx;
+    int rc = set_device(c);
+    if (rc) return rc;
+    zk_mle* o = nullptr;
+    if ((rc = new_mle(c, m->len, &o))) return rc;
+    zkk::launch_scalar_mul(o->d, m->d, s, m->len, c->stream);
+    return finish_new(c, o, out, "scalar_mul");
+}
+int zk_mle_add(const zk_mle* a, const zk_mle* b, zk_mle** out) { // _add :241-258
+    if (!a || !b || !out || a->ctx != b->ctx) return ZK_E_ARG;
+    if (a->len != b->len) return ZK_E_LEN_MISMATCH; // :244-246
+    zk_ctx* c = a->ctx;
+    int rc = set_device(c);
+    if (rc) return rc;
+    zk_mle* o = nullptr;
+    if ((rc = new_mle(c, a->len, &o))) return rc;
+    zkk::launch_add(o->d, a->d, b->d, a->len, c->stream);
+    return finish_new(c, o, out, "add");
+}
+
+// ---- GKRProver::generate_proof (gkr/src/prover.rs:24-154) ----------------------------------------
+int zk_gkr_prove(zk_ctx* c, zk_circuit* ci, zk_transcript* tr, const zk_mle* inputs, uint64_t* output_poly_out, uint64_t* w_evals_out,
+                 uint64_t* claims_out, uint64_t* coeffs_out, double* layer_ms_out) {
+    if (!c || !ci || !tr || !inputs || !output_poly_out || !claims_out || !coeffs_out || ci->ctx != c || inputs->ctx != c) return ZK_E_ARG;
+    const size_t L = ci->layers.size();
+    if (L == 0) return ZK_E_LAYER_OOB; // get_w_i(0) of a lone input layer: prover.rs:38-43 would proceed, but no layer to prove
+    if (L > 1 && !w_evals_out) return ZK_E_ARG;
+    int rc = set_device(c);
+    if (rc) return rc;
+
+    std::vector<zk_mle*> ev(L + 1, nullptr); // circuit_evaluations, :30
+    struct Free { std::vector<zk_mle*>& v; ~Free() { for (auto* m : v) zk_mle_free(m); } } free_ev{ev};
+    const auto t_start = std::chrono::steady_clock::now();
+    if ((rc = zk_circuit_evaluate(ci, inputs, ev.data()))) return rc;
+    const auto t_eval = std::chrono::steady_clock::now();
+
+    // every layer's relation needs 2^k_in == len(W_{i+1}) (ProductPolynomial::new panics otherwise, product_polynomial.rs:15-19)
+    size_t max_in = 2, max_out = 2;
+    for (size_t i = 0; i < L; ++i) {
+        const LayerDev& Ly = ci->layers[i];
+        if (((size_t)1 << Ly.k_in) != ev[i]->len || Ly.k_in < 1) return ZK_E_LEN_MISMATCH;
+        max_in = std::max(max_in, ev[i]->len);
+        max_out = std::max(max_out, Ly.n_out);
+    }
+    const size_t half_tab = (size_t)1 << zkk::kMaxEqVars;
+    const size_t eq_half = std::min(half_tab, std::max(max_in, max_out));
+    // scratch: wt[max_out] | Eu[max_in] | A H2 ones T0 T2 T3 [max_in each] | 4 eq half tables
+    DevBuf buf;
+    const size_t n_elems = max_out + 7 * max_in + 4 * eq_half;
+    HIPCHK(c, hipMalloc(&buf.p, n_elems * kElem));
+    uint8_t* base = (uint8_t*)buf.p;
+    auto take = [&](size_t n) { void* p = base; base += n * kElem; return p; };
+    void* wt = take(max_out);
+    void* Eu = take(max_in);
+    void *A = take(max_in), *H2 = take(max_in), *ones = take(max_in), *T0 = take(max_in), *T2 = take(max_in), *T3 = take(max_in);
+    void* eqs[4] = {take(eq_half), take(eq_half), take(eq_half), take(eq_half)};
+    zkk::launch_fill_one(ones, max_in, c->stream);
+
+    const zk_mle* W0 = ev[L]; // get_w_i(0), :43
+    const unsigned k0 = ilog2(W0->len);
+    rc = stream_le32(c, W0->d, W0->len, [&](const uint8_t* p, size_t nbytes, size_t) { tr->append(p, nbytes); }); // :46
+    if (rc) return rc;
+    if (layer_ms_out) {
+        const auto t_abs = std::chrono::steady_clock::now();
+        layer_ms_out[L] = std::chrono::duration<double, std::milli>(t_eval - t_start).count();
+        layer_ms_out[L + 1] = std::chrono::duration<double, std::milli>(t_abs - t_eval).count();
+    }
+    HIPCHK(c, hipMemcpyAsync(output_poly_out, W0->d, W0->len * kElem, hipMemcpyDeviceToHost, c->stream));
+    std::vector<uint64_t> rnd(4 * std::max<size_t>(k0, 1)); // random_values, :49-53
+    for (unsigned i = 0; i < k0; ++i) zkh::store(&rnd[4 * i], tr->sample());
+
+    Fq wb = zkh::zero(), wc = zkh::zero();
+    size_t coeff_off = 0;
+    hipEvent_t ev_a = nullptr, ev_b = nullptr;
+    if (layer_ms_out) { HIPCHK(c, hipEventCreate(&ev_a)); HIPCHK(c, hipEventCreate(&ev_b)); }
+    for (size_t layer_idx = 0; layer_idx < L; ++layer_idx) {
+        const LayerDev& Ly = ci->layers[L - 1 - layer_idx];
+        const zk_mle* Wn = ev[L - 1 - layer_idx]; // next_w_i, :125
+        const int k_in = Ly.k_in, k_out = Ly.k_out;
+        const size_t n_in = (size_t)1 << k_in;
+        if (layer_ms_out) HIPCHK(c, hipEventRecord(ev_a, c->stream));
+        Fq claim;
+        if (layer_idx == 0) {
+            // claim = W_0(rho) (:70-75); mul'/add' = predicates folded at rho over the k_out "a" variables (utils.rs:45-65)
+            std::vector<uint8_t> has(std::max<unsigned>(k0, 1), 1);
+            zk_mle* e = nullptr;
+            if ((rc = zk_mle_evaluate(W0, has.data(), rnd.data(), k0, &e))) return rc;
+            uint64_t v[4];
+            rc = zk_mle_download_mont(e, v);
+            zk_mle_free(e);
+            if (rc) return rc;
+            claim = zkh::load(v);
+            build_eq(c, wt, k_out, rnd.data(), zkh::one(), eqs[0], eqs[1]);
+        } else {
+            // r_b | r_c = halves of the previous challenges (:82-85); W_i(r_b), W_i(r_c) are the last folds of the
+            // previous layer's two phases (:87-99)
+            tr->append_fq(wb); // :102-105
+            tr->append_fq(wc);
+            const Fq alpha = tr->sample(), beta = tr->sample(); // :107-108
+            zkh::store(w_evals_out + 8 * (layer_idx - 1), wb);  // :115
+            zkh::store(w_evals_out + 8 * (layer_idx - 1) + 4, wc);
+            claim = zkh::add(zkh::mul(alpha, wb), zkh::mul(beta, wc)); // utils.rs:5-14
+            build_eq2(c, wt, k_out, rnd.data(), alpha, rnd.data() + 4 * k_out, beta, eqs); // utils.rs:16-43
+        }
+        zkh::store(claims_out + 4 * layer_idx, claim); // SumCheckProof.initial_claim_sum = the claim passed in, sumcheck/src/prover.rs:185
+
+        std::vector<uint64_t> ch(4 * 2 * (size_t)k_in);
+        uint64_t fin[16];
+        // rounds over b
+        zkk::launch_gkr_phase1(A, H2, Ly.lptr, Ly.lidx, Ly.right, Ly.op, wt, Wn->d, n_in, c->stream);
+        HIPCHK(c, hipGetLastError());
+        {
+            const void* t[4] = {A, Wn->d, H2, ones};
+            if ((rc = prove_sum2x2_dev(c, t, n_in, tr, coeffs_out + 12 * coeff_off, ch.data(), fin))) return rc;
+        }
+        const Fq wu = zkh::load(fin + 4); // W_{i+1}(u)
+        // rounds over c
+        build_eq(c, Eu, k_in, ch.data(), zkh::one(), eqs[0], eqs[1]);
+        zkk::launch_gkr_phase2(T0, T2, T3, Ly.rptr, Ly.ridx, Ly.left, Ly.op, wt, Eu, Wn->d, wu.l, n_in, c->stream);
+        HIPCHK(c, hipGetLastError());
+        {
+            const void* t[4] = {T0, Wn->d, T2, T3};
+            if ((rc = prove_sum2x2_dev(c, t, n_in, tr, coeffs_out + 12 * (coeff_off + k_in), ch.data() + 4 * k_in, fin))) return rc;
+        }
+        wb = wu;
+        wc = zkh::load(fin + 4); // W_{i+1}(v)
+        coeff_off += 2 * (size_t)k_in;
+        rnd = ch; // random_values = random_points, :143
+        if (layer_ms_out) {
+            HIPCHK(c, hipEventRecord(ev_b, c->stream));
+            HIPCHK(c, hipEventSynchronize(ev_b));
+            float ms = 0;
+            HIPCHK(c, hipEventElapsedTime(&ms, ev_a, ev_b));
+            layer_ms_out[layer_idx] = ms;
+        }
+    }
+    if (ev_a) (void)hipEventDestroy(ev_a);
+    if (ev_b) (void)hipEventDestroy(ev_b);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return ZK_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,45 @@
+// gkr_kernels.h -- launchers of the GKR layer-prover kernels (gkr_kernels.hip).
+// Device pointers to 32-byte Montgomery elements unless a name says otherwise; u32 arrays are
+// gate records / CSR indices built once per circuit on the host.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace zkk {
+
+static constexpr int kMaxEqVars = 16; // variables of one eq half-table (full tables: up to 2 x 16)
+
+// evaluate_at_input (circuit.rs:37-59), one layer: out[g] = in[left[g]] (+|*) in[right[g]] for g < n_gates,
+// 0 for n_gates <= g < n_out
+void launch_circuit_layer(const void* in, void* out, const uint32_t* left, const uint32_t* right, const uint8_t* op,
+                          size_t n_gates, size_t n_out, hipStream_t st);
+// out[o] = scale * eq(x, o), o < 2^k, x[0] belongs to the most significant bit of o (k <= kMaxEqVars);
+// x: k elements as 4 x u64 Montgomery limbs each
+void launch_eq_small(void* out, int k, const uint64_t* x, const uint64_t scale[4], hipStream_t st);
+// out[o] = hiA[o >> log_lo] * loA[o & (2^log_lo - 1)]  (+ hiB[..] * loB[..] when hiB != NULL), o < n
+void launch_eq_outer(void* out, size_t n, int log_lo, const void* hiA, const void* loA, const void* hiB, const void* loB,
+                     hipStream_t st);
+void launch_fill_one(void* out, size_t n, hipStream_t st);
+// phase 1 (the k_in "b" variables): for every b < n_b, over the gates whose LEFT input is b
+// (CSR: gate ids lidx[lptr[b] .. lptr[b+1])):
+//   A[b]  = sum_{mul gates} wt[o] * W[right]  +  sum_{add gates} wt[o]
+//   H2[b] = sum_{add gates} wt[o] * W[right]
+void launch_gkr_phase1(void* A, void* H2, const uint32_t* lptr, const uint32_t* lidx, const uint32_t* right, const uint8_t* op,
+                       const void* wt, const void* W, size_t n_b, hipStream_t st);
+// phase 2 (the k_in "c" variables), b bound to u: for every c < n_c over the gates whose RIGHT input is c:
+//   T0[c] = wu * sum_{mul gates} wt[o] * Eu[left],  T2[c] = sum_{add gates} wt[o] * Eu[left],  T3[c] = wu + W[c]
+void launch_gkr_phase2(void* T0, void* T2, void* T3, const uint32_t* rptr, const uint32_t* ridx, const uint32_t* left,
+                       const uint8_t* op, const void* wt, const void* Eu, const void* W, const uint64_t wu[4], size_t n_c,
+                       hipStream_t st);
+// the reference's dense tables (small circuits / API parity)
+// get_gate_poly (circuit.rs:82-123): out has n_out << 2*k_in entries, zero except 1 at (o << 2k_in | l << k_in | r)
+void launch_gate_poly(void* out, size_t n_total, const uint32_t* left, const uint32_t* right, const uint8_t* op, size_t n_gates,
+                      int k_in, int want_op, hipStream_t st);
+// operate_w (evaluation_form.rs:82-112): out[i] = wb[i / L] (+|*) wc[i % L], L = len, i < L*L
+void launch_w_op(void* out, const void* wb, const void* wc, size_t L, int mul, hipStream_t st);
+// scalar_mul (:151-153) and _add (:241-258)
+void launch_scalar_mul(void* out, const void* in, const uint64_t s[4], size_t n, hipStream_t st);
+void launch_add(void* out, const void* a, const void* b, size_t n, hipStream_t st);
+
+} // namespace zkk

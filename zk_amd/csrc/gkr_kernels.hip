@@ -1,0 +1,192 @@
+// gkr_kernels.hip -- gfx950 kernels of the GKR layer prover (gkr/src/prover.rs:24-154).
+//
+// The reference builds DENSE indicator tables add_i/mul_i of 2^(k_out + 2 k_in) entries
+// (circuit.rs:82-123) and runs the degree-2 sumcheck over the 2^(2 k_in)-entry tables
+// mul'(b,c), W(b)W(c), add'(b,c), W(b)+W(c).  Here the wiring stays a gate list.  With
+//   wt[o]   = eq(rho, o)                              (layer 0, utils.rs:45-65)
+//           = alpha*eq(r_b, o) + beta*eq(r_c, o)      (later layers, utils.rs:16-43)
+// the folded predicates are  mul'(b,c) = sum_{mul gates g} wt[o_g] [b = l_g][c = r_g]  (add' alike), and
+// the layer relation sums over c (first k_in rounds) resp. is evaluated at b = u (last k_in rounds) in
+// closed form: the round polynomials are the SAME field elements as the dense computation yields
+// (exact arithmetic), from tables of 2^k_in entries.  All kernels are gathers over small tables
+// (<= a few MiB per layer): latency-, not bandwidth-bound.
+#include "fq_dev.hpp"
+#include "gkr_kernels.h"
+
+namespace zkk {
+
+static constexpr int kT = 256;
+
+static inline int grid1d(size_t n) {
+    size_t b = (n + kT - 1) / kT;
+    if (b < 1) b = 1;
+    if (b > 65535) b = 65535;
+    return (int)b;
+}
+static inline fq to_fq4(const uint64_t r[4]) {
+    fq f;
+    for (int i = 0; i < 4; ++i) {
+        f.v[2 * i] = (u32)r[i];
+        f.v[2 * i + 1] = (u32)(r[i] >> 32);
+    }
+    return f;
+}
+__device__ __forceinline__ fq fq_one_mont() {
+    const fq one = {FQ_R_LIMBS};
+    return one;
+}
+
+__global__ void __launch_bounds__(kT) k_circuit_layer(const fq* __restrict__ in, fq* __restrict__ out, const u32* __restrict__ left,
+                                                      const u32* __restrict__ right, const uint8_t* __restrict__ op, size_t n_gates,
+                                                      size_t n_out) {
+    const size_t stride = (size_t)gridDim.x * kT;
+    for (size_t g = (size_t)blockIdx.x * kT + threadIdx.x; g < n_out; g += stride) {
+        fq o = fq_zero();
+        if (g < n_gates) {
+            const fq a = fq_load(in + left[g]), b = fq_load(in + right[g]);
+            o = op[g] ? fq_mul(a, b) : fq_add(a, b);
+        }
+        fq_store(out + g, o);
+    }
+}
+
+struct EqPts { fq x[kMaxEqVars]; fq scale; };
+__global__ void __launch_bounds__(kT) k_eq_small(fq* __restrict__ out, int k, EqPts P) {
+    const fq one = fq_one_mont();
+    const size_t n = (size_t)1 << k, stride = (size_t)gridDim.x * kT;
+    for (size_t o = (size_t)blockIdx.x * kT + threadIdx.x; o < n; o += stride) {
+        fq acc = P.scale;
+        for (int m = 0; m < k; ++m) { // x[m] <-> bit (k-1-m) of o
+            const fq xm = P.x[m];
+            const fq f = ((o >> (k - 1 - m)) & 1) ? xm : fq_sub(one, xm);
+            acc = fq_mul(acc, f);
+        }
+        fq_store(out + o, acc);
+    }
+}
+
+__global__ void __launch_bounds__(kT) k_eq_outer(fq* __restrict__ out, size_t n, int log_lo, const fq* __restrict__ hiA,
+                                                 const fq* __restrict__ loA, const fq* __restrict__ hiB, const fq* __restrict__ loB) {
+    const size_t mask = ((size_t)1 << log_lo) - 1, stride = (size_t)gridDim.x * kT;
+    for (size_t o = (size_t)blockIdx.x * kT + threadIdx.x; o < n; o += stride) {
+        fq v = fq_mul(fq_load(hiA + (o >> log_lo)), fq_load(loA + (o & mask)));
+        if (hiB) v = fq_add(v, fq_mul(fq_load(hiB + (o >> log_lo)), fq_load(loB + (o & mask))));
+        fq_store(out + o, v);
+    }
+}
+
+__global__ void __launch_bounds__(kT) k_fill_one(fq* __restrict__ out, size_t n) {
+    const fq one = fq_one_mont();
+    const size_t stride = (size_t)gridDim.x * kT;
+    for (size_t i = (size_t)blockIdx.x * kT + threadIdx.x; i < n; i += stride) fq_store(out + i, one);
+}
+
+__global__ void __launch_bounds__(kT) k_gkr_phase1(fq* __restrict__ A, fq* __restrict__ H2, const u32* __restrict__ lptr,
+                                                   const u32* __restrict__ lidx, const u32* __restrict__ right,
+                                                   const uint8_t* __restrict__ op, const fq* __restrict__ wt, const fq* __restrict__ W,
+                                                   size_t n_b) {
+    const size_t stride = (size_t)gridDim.x * kT;
+    for (size_t b = (size_t)blockIdx.x * kT + threadIdx.x; b < n_b; b += stride) {
+        fq a = fq_zero(), h2 = fq_zero();
+        for (u32 e = lptr[b]; e < lptr[b + 1]; ++e) {
+            const u32 g = lidx[e]; // the gate's output index
+            const fq w = fq_load(wt + g);
+            const fq t = fq_mul(w, fq_load(W + right[g]));
+            if (op[g]) a = fq_add(a, t);
+            else { a = fq_add(a, w); h2 = fq_add(h2, t); }
+        }
+        fq_store(A + b, a);
+        fq_store(H2 + b, h2);
+    }
+}
+
+__global__ void __launch_bounds__(kT) k_gkr_phase2(fq* __restrict__ T0, fq* __restrict__ T2, fq* __restrict__ T3,
+                                                   const u32* __restrict__ rptr, const u32* __restrict__ ridx,
+                                                   const u32* __restrict__ left, const uint8_t* __restrict__ op,
+                                                   const fq* __restrict__ wt, const fq* __restrict__ Eu, const fq* __restrict__ W, fq wu,
+                                                   size_t n_c) {
+    const size_t stride = (size_t)gridDim.x * kT;
+    for (size_t c = (size_t)blockIdx.x * kT + threadIdx.x; c < n_c; c += stride) {
+        fq m = fq_zero(), ad = fq_zero();
+        for (u32 e = rptr[c]; e < rptr[c + 1]; ++e) {
+            const u32 g = ridx[e];
+            const fq t = fq_mul(fq_load(wt + g), fq_load(Eu + left[g]));
+            if (op[g]) m = fq_add(m, t);
+            else ad = fq_add(ad, t);
+        }
+        fq_store(T0 + c, fq_mul(m, wu));
+        fq_store(T2 + c, ad);
+        fq_store(T3 + c, fq_add(wu, fq_load(W + c)));
+    }
+}
+
+__global__ void __launch_bounds__(kT) k_gate_poly(fq* __restrict__ out, const u32* __restrict__ left, const u32* __restrict__ right,
+                                                  const uint8_t* __restrict__ op, size_t n_gates, int k_in, int want_op) {
+    const fq one = fq_one_mont();
+    const size_t stride = (size_t)gridDim.x * kT;
+    for (size_t g = (size_t)blockIdx.x * kT + threadIdx.x; g < n_gates; g += stride)
+        if ((int)op[g] == want_op) fq_store(out + ((((g << k_in) | left[g]) << k_in) | right[g]), one); // get_bit_idx, circuit.rs:66-74
+}
+
+__global__ void __launch_bounds__(kT) k_w_op(fq* __restrict__ out, const fq* __restrict__ wb, const fq* __restrict__ wc, size_t L, int log_L,
+                                             int mul) {
+    const size_t n = L * L, stride = (size_t)gridDim.x * kT;
+    for (size_t i = (size_t)blockIdx.x * kT + threadIdx.x; i < n; i += stride) {
+        const fq a = fq_load(wb + (i >> log_L)), b = fq_load(wc + (i & (L - 1)));
+        fq_store(out + i, mul ? fq_mul(a, b) : fq_add(a, b));
+    }
+}
+
+__global__ void __launch_bounds__(kT) k_scalar_mul(fq* __restrict__ out, const fq* __restrict__ in, fq s, size_t n) {
+    const size_t stride = (size_t)gridDim.x * kT;
+    for (size_t i = (size_t)blockIdx.x * kT + threadIdx.x; i < n; i += stride) fq_store(out + i, fq_mul_uniform(fq_load(in + i), s));
+}
+__global__ void __launch_bounds__(kT) k_add(fq* __restrict__ out, const fq* __restrict__ a, const fq* __restrict__ b, size_t n) {
+    const size_t stride = (size_t)gridDim.x * kT;
+    for (size_t i = (size_t)blockIdx.x * kT + threadIdx.x; i < n; i += stride) fq_store(out + i, fq_add(fq_load(a + i), fq_load(b + i)));
+}
+
+// ---- launchers -------------------------------------------------------------------------------
+void launch_circuit_layer(const void* in, void* out, const uint32_t* left, const uint32_t* right, const uint8_t* op, size_t n_gates,
+                          size_t n_out, hipStream_t st) {
+    hipLaunchKernelGGL(k_circuit_layer, dim3(grid1d(n_out)), dim3(kT), 0, st, (const fq*)in, (fq*)out, left, right, op, n_gates, n_out);
+}
+void launch_eq_small(void* out, int k, const uint64_t* x, const uint64_t scale[4], hipStream_t st) {
+    EqPts P;
+    for (int m = 0; m < kMaxEqVars; ++m) P.x[m] = m < k ? to_fq4(x + 4 * m) : to_fq4(scale);
+    P.scale = to_fq4(scale);
+    hipLaunchKernelGGL(k_eq_small, dim3(grid1d((size_t)1 << k)), dim3(kT), 0, st, (fq*)out, k, P);
+}
+void launch_eq_outer(void* out, size_t n, int log_lo, const void* hiA, const void* loA, const void* hiB, const void* loB, hipStream_t st) {
+    hipLaunchKernelGGL(k_eq_outer, dim3(grid1d(n)), dim3(kT), 0, st, (fq*)out, n, log_lo, (const fq*)hiA, (const fq*)loA, (const fq*)hiB,
+                       (const fq*)loB);
+}
+void launch_fill_one(void* out, size_t n, hipStream_t st) { hipLaunchKernelGGL(k_fill_one, dim3(grid1d(n)), dim3(kT), 0, st, (fq*)out, n); }
+void launch_gkr_phase1(void* A, void* H2, const uint32_t* lptr, const uint32_t* lidx, const uint32_t* right, const uint8_t* op,
+                       const void* wt, const void* W, size_t n_b, hipStream_t st) {
+    hipLaunchKernelGGL(k_gkr_phase1, dim3(grid1d(n_b)), dim3(kT), 0, st, (fq*)A, (fq*)H2, lptr, lidx, right, op, (const fq*)wt, (const fq*)W,
+                       n_b);
+}
+void launch_gkr_phase2(void* T0, void* T2, void* T3, const uint32_t* rptr, const uint32_t* ridx, const uint32_t* left, const uint8_t* op,
+                       const void* wt, const void* Eu, const void* W, const uint64_t wu[4], size_t n_c, hipStream_t st) {
+    hipLaunchKernelGGL(k_gkr_phase2, dim3(grid1d(n_c)), dim3(kT), 0, st, (fq*)T0, (fq*)T2, (fq*)T3, rptr, ridx, left, op, (const fq*)wt,
+                       (const fq*)Eu, (const fq*)W, to_fq4(wu), n_c);
+}
+void launch_gate_poly(void* out, size_t n_total, const uint32_t* left, const uint32_t* right, const uint8_t* op, size_t n_gates, int k_in,
+                      int want_op, hipStream_t st) {
+    (void)hipMemsetAsync(out, 0, n_total * sizeof(fq), st);
+    if (n_gates) hipLaunchKernelGGL(k_gate_poly, dim3(grid1d(n_gates)), dim3(kT), 0, st, (fq*)out, left, right, op, n_gates, k_in, want_op);
+}
+void launch_w_op(void* out, const void* wb, const void* wc, size_t L, int mul, hipStream_t st) {
+    int log_L = 0;
+    while (((size_t)1 << log_L) < L) ++log_L;
+    hipLaunchKernelGGL(k_w_op, dim3(grid1d(L * L)), dim3(kT), 0, st, (fq*)out, (const fq*)wb, (const fq*)wc, L, log_L, mul);
+}
+void launch_scalar_mul(void* out, const void* in, const uint64_t s[4], size_t n, hipStream_t st) {
+    hipLaunchKernelGGL(k_scalar_mul, dim3(grid1d(n)), dim3(kT), 0, st, (fq*)out, (const fq*)in, to_fq4(s), n);
+}
+void launch_add(void* out, const void* a, const void* b, size_t n, hipStream_t st) {
+    hipLaunchKernelGGL(k_add, dim3(grid1d(n)), dim3(kT), 0, st, (fq*)out, (const fq*)a, (const fq*)b, n);
+}
+
+} // namespace zkk

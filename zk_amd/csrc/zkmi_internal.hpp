@@ -1,0 +1,232 @@
+// zkmi_internal.hpp -- structs and helpers shared by the translation units of libzkmi.so
+// (zkmi.cpp: contexts, tables, sumcheck provers; gkr.cpp: circuit + GKR layer prover).
+#pragma once
+#include "../../include/zkmi.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "fq_host.hpp"
+#include "keccak_host.hpp"
+#include "kernels.h"
+
+using zkh::Fq;
+
+namespace zki {
+constexpr size_t kElem = 32;
+constexpr size_t kChunkElems = (size_t)1 << 21; // 64 MiB staging chunks for byte conversion
+constexpr size_t kSums = 16;                    // 2^kMaxFoldBatch block sums per pass
+
+inline bool is_pow2(size_t n) { return n && !(n & (n - 1)); }
+inline unsigned ilog2(size_t n) {
+    unsigned k = 0;
+    while (n > 1) { n >>= 1; ++k; }
+    return k;
+}
+} // namespace zki
+using namespace zki;
+
+struct zk_transcript {
+    zkh::Keccak256 hasher;
+    void append(const uint8_t* d, size_t n) { hasher.update(d, n); }
+    void append_fq(const Fq& v) {
+        uint8_t b[32];
+        zkh::to_le32(v, b);
+        hasher.update(b, 32);
+    }
+    Fq sample() { // transcript.rs:28-36
+        uint8_t h[32];
+        hasher.peek(h);
+        hasher.update(h, 32);
+        return zkh::from_le32_mod_order(h);
+    }
+};
+
+struct ProfSlot { int kernel; hipEvent_t a, b; uint64_t bytes; };
+
+struct zk_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = true;     // false: the caller's stream (zk_ctx_create_on_stream)
+    void* partials = nullptr;   // kMaxBlocks * 3 elements
+    void* sums_dev = nullptr;   // kSums elements
+    uint64_t* sums_host = nullptr; // pinned, kSums elements
+    int fold_batch = 4;          // rounds bound per device pass (1..kMaxFoldBatch)
+    bool double_buffer = false;  // register double-buffering in k_multifold (tree variant)
+    bool lazy = true;            // inner-product form with one reduction per output (k_multifold_lazy)
+    int lazy_group = 4;          // elements per register load buffer in k_multifold_lazy (2 or 4)
+    void* work[2] = {nullptr, nullptr};
+    size_t work_cap[2] = {0, 0}; // bytes
+    void* stage = nullptr;       // kChunkElems elements
+    std::string err;
+    bool prof_on = false;
+    std::vector<ProfSlot> prof_pending;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_free;
+    uint64_t prof_launches[ZK_K_COUNT] = {0};
+    double prof_ms[ZK_K_COUNT] = {0};
+    uint64_t prof_bytes[ZK_K_COUNT] = {0};
+};
+
+struct zk_mle {
+    zk_ctx* ctx;
+    void* d;
+    size_t len;
+    bool owned;
+    int device; // copy of ctx->device: freeing a table must not touch a context that is already gone
+};
+
+#define HIPCHK(ctx, call)                                                                           \
+    do {                                                                                            \
+        hipError_t e_ = (call);                                                                     \
+        if (e_ != hipSuccess) {                                                                     \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                         \
+            return ZK_E_HIP;                                                                        \
+        }                                                                                           \
+    } while (0)
+
+namespace zki {
+
+inline int set_device(zk_ctx* c) { HIPCHK(c, hipSetDevice(c->device)); return ZK_OK; }
+
+inline int ensure_work(zk_ctx* c, int which, size_t bytes) {
+    if (c->work_cap[which] >= bytes) return ZK_OK;
+    if (c->work[which]) { HIPCHK(c, hipFree(c->work[which])); c->work[which] = nullptr; c->work_cap[which] = 0; }
+    HIPCHK(c, hipMalloc(&c->work[which], bytes));
+    c->work_cap[which] = bytes;
+    return ZK_OK;
+}
+inline int ensure_stage(zk_ctx* c) {
+    if (!c->stage) HIPCHK(c, hipMalloc(&c->stage, kChunkElems * kElem));
+    return ZK_OK;
+}
+
+// ---- profiling brackets -------------------------------------------------------------------
+struct ProfScope {
+    zk_ctx* c;
+    bool active;
+    ProfSlot slot;
+    ProfScope(zk_ctx* ctx, int kernel, uint64_t bytes) : c(ctx), active(ctx->prof_on) {
+        if (!active) return;
+        slot.kernel = kernel;
+        slot.bytes = bytes;
+        if (!c->prof_free.empty()) {
+            slot.a = c->prof_free.back().first;
+            slot.b = c->prof_free.back().second;
+            c->prof_free.pop_back();
+        } else if (hipEventCreate(&slot.a) != hipSuccess || hipEventCreate(&slot.b) != hipSuccess) {
+            active = false;
+            return;
+        }
+        (void)hipEventRecord(slot.a, c->stream);
+    }
+    ~ProfScope() {
+        if (!active) return;
+        (void)hipEventRecord(slot.b, c->stream);
+        c->prof_pending.push_back(slot);
+    }
+};
+// call only after the stream has been synchronized
+inline void prof_collect(zk_ctx* c) {
+    for (auto& s : c->prof_pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
+            c->prof_launches[s.kernel] += 1;
+            c->prof_ms[s.kernel] += ms;
+            c->prof_bytes[s.kernel] += s.bytes;
+        }
+        c->prof_free.emplace_back(s.a, s.b);
+    }
+    c->prof_pending.clear();
+}
+
+// second stage + device->host of ns sums; blocks until they are on the host
+inline int fetch_sums(zk_ctx* c, int nblocks, int ns, Fq* out) {
+    zkk::launch_reduce_partials(c->partials, nblocks, ns, c->sums_dev, c->stream);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(c->sums_host, c->sums_dev, (size_t)ns * kElem, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int s = 0; s < ns; ++s) out[s] = zkh::load(c->sums_host + 4 * s);
+    return ZK_OK;
+}
+
+// device->host of the ns block sums a launch_block_sums / launch_multifold left in sums_dev
+inline int fetch_block_sums(zk_ctx* c, int ns, Fq* out) {
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(c->sums_host, c->sums_dev, (size_t)ns * kElem, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int s = 0; s < ns; ++s) out[s] = zkh::load(c->sums_host + 4 * s);
+    return ZK_OK;
+}
+
+// eq(r, b) * 2^280 mod p for all b < 2^m as 10 x 28-bit limbs each; r[l] (Montgomery, 4 limbs each)
+// belongs to bit (m-1-l) of b: variable 0 is the most significant index bit (evaluation_form.rs:40-42)
+inline void eq_weights28(const uint64_t* rs, unsigned m, uint32_t* w28) {
+    Fq eq[1 << zkk::kMaxFoldBatch];
+    eq[0] = zkh::one();
+    unsigned n = 1;
+    for (unsigned l = 0; l < m; ++l) { // append variable l as the new least significant bit
+        const Fq r = zkh::load(rs + 4 * l), one_minus_r = zkh::sub(zkh::one(), r);
+        for (unsigned b = n; b-- > 0;) {
+            eq[2 * b + 1] = zkh::mul(eq[b], r);
+            eq[2 * b] = zkh::mul(eq[b], one_minus_r);
+        }
+        n *= 2;
+    }
+    // eq[b] holds eq*2^256 mod p; one more Montgomery product by (2^24 in Montgomery form) gives the
+    // plain integer eq * 2^280 mod p
+    const Fq two24 = zkh::from_u64((uint64_t)1 << 24);
+    for (unsigned b = 0; b < n; ++b) {
+        const Fq v = zkh::mul(eq[b], two24);
+        for (int j = 0; j < 10; ++j) {
+            const unsigned bit = 28 * j, w = bit / 64, sh = bit % 64;
+            uint64_t x = v.l[w] >> sh;
+            if (sh > 36 && w + 1 < 4) x |= v.l[w + 1] << (64 - sh);
+            w28[b * 10 + j] = (uint32_t)(x & 0x0fffffffu);
+        }
+    }
+}
+
+inline int new_mle(zk_ctx* c, size_t len, zk_mle** out) {
+    if (!is_pow2(len)) return ZK_E_NOT_POW2; // evaluation_form.rs:23-27
+    zk_mle* m = new (std::nothrow) zk_mle{c, nullptr, len, true, c->device};
+    if (!m) return ZK_E_ALLOC;
+    hipError_t e = hipMalloc(&m->d, len * kElem);
+    if (e != hipSuccess) {
+        c->err = std::string("hipMalloc table: ") + hipGetErrorString(e);
+        delete m;
+        return ZK_E_ALLOC;
+    }
+    *out = m;
+    return ZK_OK;
+}
+
+// to_bytes of a table fed to `sink` in chunks (device converts, host receives LE32 bytes)
+template <class Sink>
+int stream_le32(zk_ctx* c, const void* table, size_t len, Sink&& sink) {
+    int rc = ensure_stage(c);
+    if (rc) return rc;
+    std::vector<uint8_t> host(std::min(len, kChunkElems) * kElem);
+    for (size_t off = 0; off < len; off += kChunkElems) {
+        size_t n = std::min(kChunkElems, len - off);
+        zkk::launch_to_le32((const uint8_t*)table + off * kElem, c->stage, n, c->stream);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipMemcpyAsync(host.data(), c->stage, n * kElem, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        sink(host.data(), n * kElem, off);
+    }
+    return ZK_OK;
+}
+
+// defined in zkmi.cpp
+int prove_sum2x2_dev(zk_ctx* c, const void* const tables[4], size_t len, zk_transcript* tr, uint64_t* coeffs_out,
+                     uint64_t* challenges_out, uint64_t* final_out);
+
+} // namespace zki
+using namespace zki;

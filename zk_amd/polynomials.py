@@ -115,6 +115,26 @@ class MultiLinearPolynomial:
         check(lib().zk_mle_evaluation_sum(self.h, out.ctypes.data_as(u64p)), self.ctx.h)
         return out
 
+    def _binary(self, fn, other):
+        h = C.c_void_p()
+        check(fn(self.h, other.h, C.byref(h)), self.ctx.h)
+        return MultiLinearPolynomial(ctx=self.ctx, _handle=h)
+
+    @staticmethod
+    def w_add(w_b, w_c):                       # :303-308
+        return w_b._binary(lib().zk_mle_w_add, w_c)
+
+    def w_mul(self, other):                    # :310-312 -- operate_w(other, self, Mul)
+        return self._binary(lib().zk_mle_w_mul, other)
+
+    def scalar_mul(self, scalar):              # :151-153
+        h = C.c_void_p()
+        check(lib().zk_mle_scalar_mul(self.h, _limbs(scalar).ctypes.data_as(u64p), C.byref(h)), self.ctx.h)
+        return MultiLinearPolynomial(ctx=self.ctx, _handle=h)
+
+    def __add__(self, other):                  # _add / impl Add :241-258, :303-313
+        return self._binary(lib().zk_mle_add, other)
+
     def round_sums(self) -> np.ndarray:
         """(e0, e1) of sumcheck/src/prover.rs:108-116 as a (2,4) array."""
         out = np.empty((2, 4), dtype=np.uint64)
