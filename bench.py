@@ -248,8 +248,8 @@ def bench_sharded(args, zk_amd, np, dist, rank, local_rank, world):
 
     from zk_amd import sharded
 
-    if args.workload != "mle":
-        raise SystemExit("multi-GPU bench: --workload mle only")
+    if args.workload not in ("mle", "sum2x2"):
+        raise SystemExit("multi-GPU bench: --workload mle or sum2x2")
     g = world.bit_length() - 1
     if world != 1 << g:
         raise SystemExit("world size must be a power of two")
@@ -259,16 +259,34 @@ def bench_sharded(args, zk_amd, np, dist, rank, local_rank, world):
     if args.fold_batch:
         ctx.set_fold_batch(args.fold_batch, args.fold_variant)
     fold_batch = args.fold_batch or sharded.MAX_FOLD_BATCH
-    poly = zk_amd.MultiLinearPolynomial.generate(SEED, n_local, first=rank, step=world, ctx=ctx)
     base = zk_amd.Transcript()
     base.append(b"bench: table absorb skipped (sharded run; SURVEY.md H1)")
+    if args.workload == "mle":
+        poly = zk_amd.MultiLinearPolynomial.generate(SEED, n_local, first=rank, step=world, ctx=ctx)
 
-    def step():
-        sh = sharded.DeviceShard(poly)
-        try:
-            return sharded.generate_round_polys_sharded(sh, base.clone(), world, dist, None, fold_batch)
-        finally:
-            sh.close()
+        def step():
+            sh = sharded.DeviceShard(poly)
+            try:
+                return sharded.generate_round_polys_sharded(sh, base.clone(), world, dist, None, fold_batch)
+            finally:
+                sh.close()
+
+        dom_kernel, names = "multifold", ("block_sums", "multifold")
+        what = f"single-MLE sumcheck, 2^{log_total} entries"
+        exchange = f"all-gather of 2^m block sums per pass ({dist.get_backend()}), {fold_batch} rounds per pass"
+    else:
+        tabs = [zk_amd.MultiLinearPolynomial.generate(SEED + k, n_local, first=rank, step=world, ctx=ctx) for k in range(4)]
+
+        def step():
+            sh = sharded.DeviceShard4(tabs)
+            try:
+                return sharded.generate_round_polys_sum2x2_sharded(sh, base.clone(), world, dist, None)
+            finally:
+                sh.close()
+
+        dom_kernel, names = "fold4_eval3", ("eval3", "fold4_eval3")
+        what = f"degree-2 sumcheck Sum[Prod[f,g],Prod[h,k]], 4 x 2^{log_total} entries"
+        exchange = f"all-gather of 3 evaluation shares per round ({dist.get_backend()})"
 
     for _ in range(args.warmup):
         step()
@@ -301,7 +319,7 @@ def bench_sharded(args, zk_amd, np, dist, rank, local_rank, world):
     ms_per_step = float(tmax.item()) * 1e3 / args.steps
 
     kernels = {}
-    for name in ("block_sums", "multifold"):
+    for name in names:
         p = ctx.prof_read(name)
         if p["launches"]:
             kernels[name] = {
@@ -309,20 +327,20 @@ def bench_sharded(args, zk_amd, np, dist, rank, local_rank, world):
                 "alg_bytes_per_launch": p["alg_bytes"] / p["launches"],
                 "achieved_GBs": p["alg_bytes"] / (p["ms"] * 1e-3) / 1e9 if p["ms"] > 0 else None,
             }
-    dom = kernels["multifold"]
+    dom = kernels[dom_kernel]
     roofline = {
-        "bound": "hbm", "kernel": "multifold", "achieved": dom["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "bound": "hbm", "kernel": dom_kernel, "achieved": dom["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": dom["achieved_GBs"] / HBM_PEAK_GBS, "traffic": None,
         "note": "rank 0's launches (per GPU): algorithmic bytes of all launches of the kernel in the timed steps / "
-                "their summed HIP-event durations (32 B per input entry read + 32 B per output entry written)",
+                "their summed HIP-event durations (multifold: 32 B per input entry read + 32 B per output entry written; "
+                "fold4_eval3: 48 B per input entry per table)",
     }
     return {
         "elems_per_s": (1 << log_total) / (ms_per_step * 1e-3), "ms_per_step": ms_per_step, "roofline": roofline,
         "kernels": kernels, "proof_check": {"all_ranks_identical": same},
-        "config": {"workload": f"single-MLE sumcheck, 2^{log_total} entries sharded over {world} GPUs "
-                               f"(2^{log_total - g} per GPU, low-bit sharding)",
+        "config": {"workload": f"{what} sharded over {world} GPUs (2^{log_total - g} per GPU, low-bit sharding)",
                    "log_n": log_total, "field": "BN254 Fq", "parallelism": f"table-sharded x{world}",
-                   "exchange": f"all-gather of 2^m block sums per pass ({dist.get_backend()}), {fold_batch} rounds per pass",
+                   "exchange": exchange,
                    "transcript": "Keccak-256 on every host, one challenge per round"},
     }
 

@@ -145,6 +145,27 @@ int zk_shard_block_sums(zk_shard *s, int m, void *sums_dev_out);
  * leave the 2^m_next block sums of the result in sums_dev_out (m_next = 0: none) */
 int zk_shard_fold(zk_shard *s, int m, const uint64_t *r_mont, int m_next, void *sums_dev_out);
 
+/* The SumPolynomial branch (prover.rs:89-107, :131-139) in steps, for four factor tables sharded the same
+ * way.  Per round every rank contributes its share of the three evaluations (3 x 32 B, all-gathered by
+ * the host framework); zk_sumcheck_round_from_evals sums the shares and runs the host part of the round.
+ * After the last local round each rank holds one entry per table: these rows form four log2(world)-
+ * variable tables that zk_sumcheck_prove_sum2x2_host finishes on the host. */
+typedef struct zk_shard4 zk_shard4;
+int zk_shard4_begin(zk_ctx *ctx, zk_mle *const tables[4], zk_shard4 **out); /* tables are not modified */
+void zk_shard4_end(zk_shard4 *s);
+size_t zk_shard4_len(const zk_shard4 *s);                  /* entries left per local table */
+int zk_shard4_eval(zk_shard4 *s, void *ev_dev_out);        /* 3 elements: shares of ev(0), ev(1), ev(2) */
+/* fold all four tables at r; out_dev gets the next round's 3 shares, or -- when one entry per table is
+ * left -- those 4 entries (table order) */
+int zk_shard4_fold(zk_shard4 *s, const uint64_t r_mont[4], void *out_dev);
+/* evals: [world][3] elements; coeffs_out: the round polynomial (3 coefficients); host only */
+int zk_sumcheck_round_from_evals(zk_transcript *t, const uint64_t *evals, int world, uint64_t coeffs_out[12],
+                                 uint64_t challenge_out[4]);
+/* generate_round_polys, SumPolynomial branch, on four HOST tables of len entries (4 x len elements,
+ * table-major); coeffs_out log2(len) x 3, challenges_out log2(len) (may be NULL); host only */
+int zk_sumcheck_prove_sum2x2_host(zk_transcript *t, const uint64_t *tables, size_t len, uint64_t *coeffs_out,
+                                  uint64_t *challenges_out);
+
 /* ---- sumcheck verifier (sumcheck/src/verifier.rs) -- the parity harness ---------------- */
 /* partial_verify :29-62 (host only). */
 int zk_sumcheck_partial_verify(const uint64_t claim_mont[4], const uint64_t *coeffs, size_t n_rounds,

@@ -105,3 +105,37 @@ def test_device_shard_steps_match_oracle():
     ctx.synchronize()
     sh.close()
     assert np.array_equal(m.get_evaluation_points(), table)  # the caller's table is left unmodified
+
+
+# ---------------------------------------------------------------- degree-2 branch, sharded
+def _worker4(rank, world, port, backend, log_n, outdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    try:
+        ctx = sharded.torch_stream_context(0)
+        n = 1 << log_n
+        tabs = [zk_amd.MultiLinearPolynomial.generate(SEED + 10 + k, n // world, first=rank, step=world, ctx=ctx) for k in range(4)]
+        tr = zk_amd.Transcript()
+        tr.append(b"degree-2 sharded")
+        sh = sharded.DeviceShard4(tabs)
+        coeffs, ch = sharded.generate_round_polys_sum2x2_sharded(sh, tr, world, dist)
+        sh.close()
+        np.savez(os.path.join(outdir, f"q{rank}.npz"), coeffs=coeffs, ch=ch)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,backend,log_n", [(2, "gloo", 10), (4, "gloo", 9), (2, "gloo", 2), (1, "nccl", 8)])
+def test_sharded_degree2_on_one_gpu(tmp_path, world, backend, log_n):
+    mp.spawn(_worker4, args=(world, _free_port(), backend, log_n, str(tmp_path)), nprocs=world, join=True)
+    tabs = [O.gen_table(SEED + 10 + k, 0, 1 << log_n) for k in range(4)]
+    otr = O.OTranscript()
+    otr.append(b"degree-2 sharded")
+    oc, och = O.sumcheck_prove_sum([[tabs[0], tabs[1]], [tabs[2], tabs[3]]], O.fq1(0), otr)
+    for r in range(world):
+        d = np.load(tmp_path / f"q{r}.npz")
+        assert np.array_equal(d["coeffs"], oc) and np.array_equal(d["ch"], och), f"rank {r}"

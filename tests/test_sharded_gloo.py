@@ -109,3 +109,80 @@ def test_rounds_from_block_sums_rejects_bad_shapes():
         sharded.rounds_from_block_sums(tr, np.zeros((1, 3, 4), dtype=np.uint64))
     with pytest.raises(ValueError):
         sharded.rounds_from_block_sums(tr, np.zeros((1, 1, 4), dtype=np.uint64))
+
+
+# ---------------------------------------------------------------- degree-2 branch
+P = O.P
+
+
+class OracleShard4:
+    """Stand-in for DeviceShard4: four local tables as Python ints; evaluations and folds in big ints."""
+
+    def __init__(self, tables):
+        self.t = [O.mont_to_ints(t) for t in tables]
+
+    def local_len(self):
+        return len(self.t[0])
+
+    def new_buf(self):
+        return torch.zeros((4, 4), dtype=torch.int64)
+
+    def _put(self, vals, out):
+        a = O.ints_to_mont(vals)
+        out[: len(vals)] = torch.from_numpy(a.view(np.int64))
+
+    def eval(self, out):
+        h = len(self.t[0]) // 2
+        ev = [0, 0, 0]
+        for j in range(h):
+            lo = [t[j] for t in self.t]
+            hi = [t[j + h] for t in self.t]
+            for x in range(3):
+                v = [(lo[q] + x * (hi[q] - lo[q])) % P for q in range(4)]
+                ev[x] = (ev[x] + v[0] * v[1] + v[2] * v[3]) % P
+        self._put(ev, out)
+
+    def fold(self, r, out):
+        rr = O.mont_to_ints(np.asarray(r).reshape(1, 4))[0]
+        h = len(self.t[0]) // 2
+        self.t = [[(t[j] + (t[j + h] - t[j]) * rr) % P for j in range(h)] for t in self.t]
+        if h >= 2:
+            self.eval(out)
+        else:
+            self._put([t[0] for t in self.t], out)
+
+
+def _worker4(rank, world, port, log_n, outdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n = 1 << log_n
+        tabs = [O.gen_table(SEED + 10 + k, 0, n) for k in range(4)]
+        tr = zk_amd.Transcript()
+        tr.append(b"degree-2 sharded")
+        coeffs, ch = sharded.generate_round_polys_sum2x2_sharded(OracleShard4([t[rank::world] for t in tabs]), tr, world, dist)
+        np.savez(os.path.join(outdir, f"q{rank}.npz"), coeffs=coeffs, ch=ch, digest=np.frombuffer(tr.peek_digest(), dtype=np.uint8))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,log_n", [(2, 6), (4, 5), (2, 2), (4, 3)])
+def test_sharded_degree2_matches_unsharded_oracle(tmp_path, world, log_n):
+    mp.spawn(_worker4, args=(world, _free_port(), log_n, str(tmp_path)), nprocs=world, join=True)
+    tabs = [O.gen_table(SEED + 10 + k, 0, 1 << log_n) for k in range(4)]
+    otr = O.OTranscript()
+    otr.append(b"degree-2 sharded")
+    oc, och = O.sumcheck_prove_sum([[tabs[0], tabs[1]], [tabs[2], tabs[3]]], O.fq1(0), otr)
+    for r in range(world):
+        d = np.load(tmp_path / f"q{r}.npz")
+        assert np.array_equal(d["coeffs"], oc) and np.array_equal(d["ch"], och), f"rank {r}"
+        assert d["digest"].tobytes() == otr.peek_digest()
+
+
+def test_host_degree2_prover_matches_oracle():
+    for log_n in (1, 2, 4):
+        tabs = [O.gen_table(SEED + 20 + k, 0, 1 << log_n) for k in range(4)]
+        tr, otr = zk_amd.Transcript(), O.OTranscript()
+        c, ch = sharded.prove_sum2x2_host(tr, np.stack(tabs))
+        oc, och = O.sumcheck_prove_sum([[tabs[0], tabs[1]], [tabs[2], tabs[3]]], O.fq1(0), otr)
+        assert np.array_equal(c, oc) and np.array_equal(ch, och) and tr.peek_digest() == otr.peek_digest()

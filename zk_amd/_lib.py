@@ -62,6 +62,13 @@ SYMBOLS = [
     ("zk_shard_vars_left", C.c_int, [_VP]),
     ("zk_shard_block_sums", C.c_int, [_VP, C.c_int, _VP]),
     ("zk_shard_fold", C.c_int, [_VP, C.c_int, u64p, C.c_int, _VP]),
+    ("zk_shard4_begin", C.c_int, [_VP, C.POINTER(_VP), C.POINTER(_VP)]),
+    ("zk_shard4_end", None, [_VP]),
+    ("zk_shard4_len", C.c_size_t, [_VP]),
+    ("zk_shard4_eval", C.c_int, [_VP, _VP]),
+    ("zk_shard4_fold", C.c_int, [_VP, u64p, _VP]),
+    ("zk_sumcheck_round_from_evals", C.c_int, [_VP, u64p, C.c_int, u64p, u64p]),
+    ("zk_sumcheck_prove_sum2x2_host", C.c_int, [_VP, u64p, C.c_size_t, u64p, u64p]),
     ("zk_sumcheck_partial_verify", C.c_int, [u64p, u64p, C.c_size_t, C.c_size_t, _VP, C.POINTER(C.c_int), u64p, u64p]),
     ("zk_sumcheck_verify_mle", C.c_int, [_VP, _VP, u64p, u64p, C.c_size_t, C.POINTER(C.c_int)]),
     ("zk_mle_w_add", C.c_int, [_VP, _VP, C.POINTER(_VP)]),

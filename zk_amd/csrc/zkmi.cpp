@@ -584,6 +584,136 @@ int zk_sumcheck_prove_sum2x2(zk_ctx* c, zk_mle* const tables[4], const uint64_t 
     return prove_sum2x2_dev(c, t, len, tr, coeffs_out, challenges_out, nullptr);
 }
 
+// ---- degree-2 prover in steps (sharded tables) ---------------------------------------------------
+namespace {
+// one round of the SumPolynomial branch from the three evaluations (prover.rs:102-107, :126-135)
+Fq host_round_deg2(zk_transcript* tr, const Fq ev[3], uint64_t* coeffs_out) {
+    const Fq inv2 = zkh::inv2();
+    Fq claimed = zkh::add(ev[0], ev[1]);
+    Fq c2 = zkh::mul(zkh::add(zkh::sub(ev[0], zkh::add(ev[1], ev[1])), ev[2]), inv2);
+    Fq c1 = zkh::sub(zkh::sub(ev[1], ev[0]), c2);
+    tr->append_fq(claimed);
+    tr->append_fq(ev[0]);
+    tr->append_fq(c1);
+    tr->append_fq(c2);
+    zkh::store(coeffs_out, ev[0]);
+    zkh::store(coeffs_out + 4, c1);
+    zkh::store(coeffs_out + 8, c2);
+    return tr->sample();
+}
+} // namespace
+
+struct zk_shard4 {
+    zk_ctx* ctx;
+    const void* cur[4];
+    size_t len; // entries per table
+    int pass;
+};
+
+// evals: [world][3] partial evaluations (every rank's share of ev[0..3)); sums them, runs the round
+int zk_sumcheck_round_from_evals(zk_transcript* t, const uint64_t* evals, int world, uint64_t coeffs_out[12], uint64_t challenge_out[4]) {
+    if (!t || !evals || !coeffs_out || !challenge_out || world < 1) return ZK_E_ARG;
+    Fq ev[3] = {zkh::zero(), zkh::zero(), zkh::zero()};
+    for (int q = 0; q < world; ++q)
+        for (int x = 0; x < 3; ++x) ev[x] = zkh::add(ev[x], zkh::load(evals + 4 * (3 * (size_t)q + x)));
+    zkh::store(challenge_out, host_round_deg2(t, ev, coeffs_out));
+    return ZK_OK;
+}
+
+// the whole SumPolynomial-branch round loop on four small HOST tables (the tail of a sharded prove:
+// one entry per rank and table).  tables: 4 x len elements; coeffs_out log2(len) x 3.
+int zk_sumcheck_prove_sum2x2_host(zk_transcript* t, const uint64_t* tables, size_t len, uint64_t* coeffs_out, uint64_t* challenges_out) {
+    if (!t || !tables) return ZK_E_ARG;
+    if (!is_pow2(len)) return ZK_E_NOT_POW2;
+    const unsigned n = ilog2(len);
+    if (n && !coeffs_out) return ZK_E_ARG;
+    std::vector<Fq> T(4 * len);
+    for (size_t i = 0; i < 4 * len; ++i) T[i] = zkh::load(tables + 4 * i);
+    size_t cur = len;
+    for (unsigned k = 0; k < n; ++k) {
+        const size_t half = cur / 2;
+        Fq ev[3] = {zkh::zero(), zkh::zero(), zkh::zero()};
+        for (size_t j = 0; j < half; ++j) {
+            Fq lo[4], hi[4], x2[4];
+            for (int q = 0; q < 4; ++q) {
+                lo[q] = T[q * len + j];
+                hi[q] = T[q * len + half + j];
+                x2[q] = zkh::sub(zkh::add(hi[q], hi[q]), lo[q]); // lo + 2 (hi - lo)
+            }
+            ev[0] = zkh::add(ev[0], zkh::add(zkh::mul(lo[0], lo[1]), zkh::mul(lo[2], lo[3])));
+            ev[1] = zkh::add(ev[1], zkh::add(zkh::mul(hi[0], hi[1]), zkh::mul(hi[2], hi[3])));
+            ev[2] = zkh::add(ev[2], zkh::add(zkh::mul(x2[0], x2[1]), zkh::mul(x2[2], x2[3])));
+        }
+        const Fq r = host_round_deg2(t, ev, coeffs_out + 12 * k);
+        if (challenges_out) zkh::store(challenges_out + 4 * k, r);
+        for (int q = 0; q < 4; ++q)
+            for (size_t j = 0; j < half; ++j)
+                T[q * len + j] = zkh::add(T[q * len + j], zkh::mul(zkh::sub(T[q * len + half + j], T[q * len + j]), r));
+        cur = half;
+    }
+    return ZK_OK;
+}
+
+int zk_shard4_begin(zk_ctx* c, zk_mle* const tables[4], zk_shard4** out) {
+    if (!c || !tables || !out) return ZK_E_ARG;
+    for (int k = 0; k < 4; ++k)
+        if (!tables[k] || tables[k]->ctx != c) return ZK_E_ARG;
+    for (int k = 1; k < 4; ++k)
+        if (tables[k]->len != tables[0]->len) return ZK_E_LEN_MISMATCH;
+    zk_shard4* s = new (std::nothrow) zk_shard4{c, {tables[0]->d, tables[1]->d, tables[2]->d, tables[3]->d}, tables[0]->len, 0};
+    if (!s) return ZK_E_ALLOC;
+    *out = s;
+    return ZK_OK;
+}
+void zk_shard4_end(zk_shard4* s) { delete s; }
+size_t zk_shard4_len(const zk_shard4* s) { return s ? s->len : 0; }
+
+// ev_dev_out (3 elements) = this rank's share of the three evaluations of the current tables; asynchronous
+int zk_shard4_eval(zk_shard4* s, void* ev_dev_out) {
+    if (!s || !ev_dev_out || s->len < 2) return ZK_E_ARG;
+    zk_ctx* c = s->ctx;
+    int rc = set_device(c);
+    if (rc) return rc;
+    int g;
+    {
+        ProfScope ps(c, ZK_K_EVAL3, (uint64_t)s->len * 32 * 4);
+        g = zkk::launch_eval3(s->cur, s->len / 2, c->partials, c->stream);
+    }
+    zkk::launch_reduce_partials(c->partials, g, 3, ev_dev_out, c->stream);
+    HIPCHK(c, hipGetLastError());
+    return ZK_OK;
+}
+
+// fold the four tables at r (prover.rs:131-139).  While more than one entry per table remains, out_dev
+// (3 elements) receives the next round's evaluation shares; when the fold leaves ONE entry per table,
+// out_dev (4 elements) receives those entries instead (the rank's row of the tail tables).
+int zk_shard4_fold(zk_shard4* s, const uint64_t r[4], void* out_dev) {
+    if (!s || !r || !out_dev || s->len < 2) return ZK_E_ARG;
+    zk_ctx* c = s->ctx;
+    int rc = set_device(c);
+    if (rc) return rc;
+    const size_t outlen = s->len / 2;
+    if ((rc = ensure_work(c, s->pass & 1, 4 * outlen * kElem))) return rc;
+    void* dst[4];
+    for (int t = 0; t < 4; ++t) dst[t] = (uint8_t*)c->work[s->pass & 1] + (size_t)t * outlen * kElem;
+    if (outlen >= 2) {
+        int g;
+        {
+            ProfScope ps(c, ZK_K_FOLD4_EVAL3, (uint64_t)s->len * 48 * 4);
+            g = zkk::launch_fold4_eval3(s->cur, dst, s->len / 4, r, c->partials, c->stream);
+        }
+        zkk::launch_reduce_partials(c->partials, g, 3, out_dev, c->stream);
+    } else {
+        zkk::launch_fold4(s->cur, dst, outlen, r, c->stream);
+        HIPCHK(c, hipMemcpyAsync(out_dev, c->work[s->pass & 1], 4 * kElem, hipMemcpyDeviceToDevice, c->stream));
+    }
+    HIPCHK(c, hipGetLastError());
+    for (int t = 0; t < 4; ++t) s->cur[t] = dst[t];
+    s->len = outlen;
+    ++s->pass;
+    return ZK_OK;
+}
+
 // ---- verifier ------------------------------------------------------------------------------------
 int zk_sumcheck_partial_verify(const uint64_t claim[4], const uint64_t* coeffs, size_t n_rounds, size_t ncoef,
                                zk_transcript* tr, int* ok_out, uint64_t final_claim_out[4], uint64_t* challenges_out) {

@@ -182,3 +182,89 @@ def torch_stream_context(local_rank: int) -> Context:
 
     torch.cuda.set_device(local_rank)
     return Context.on_stream(local_rank, torch.cuda.current_stream().cuda_stream)
+
+
+# ---------------------------------------------------------------- degree-2 (SumPolynomial branch)
+class DeviceShard4:
+    """This rank's shards of the four factor tables of Sum[Prod[t0,t1], Prod[t2,t3]] (zk_shard4)."""
+
+    def __init__(self, tables):
+        import torch
+
+        self._torch = torch
+        self.tables = list(tables)
+        self.ctx = self.tables[0].ctx
+        arr = (C.c_void_p * 4)(*[t.h for t in self.tables])
+        h = C.c_void_p()
+        check(lib().zk_shard4_begin(self.ctx.h, arr, C.byref(h)), self.ctx.h)
+        self.h = h
+
+    def local_len(self) -> int:
+        return lib().zk_shard4_len(self.h)
+
+    def new_buf(self):
+        return self._torch.empty((4, 4), dtype=self._torch.int64, device=self._torch.device("cuda", self.ctx.device_id))
+
+    def eval(self, out) -> None:
+        check(lib().zk_shard4_eval(self.h, C.c_void_p(out.data_ptr())), self.ctx.h)
+
+    def fold(self, r: np.ndarray, out) -> None:
+        r = np.ascontiguousarray(r, dtype=np.uint64)
+        check(lib().zk_shard4_fold(self.h, _ptr(r), C.c_void_p(out.data_ptr())), self.ctx.h)
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().zk_shard4_end(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def round_from_evals(transcript: Transcript, evals: np.ndarray):
+    """evals (world, 3, 4) -> (coefficients (3,4), challenge (4,)); zk_sumcheck_round_from_evals, host only."""
+    evals = np.ascontiguousarray(evals, dtype=np.uint64)
+    coeffs = np.empty((3, 4), dtype=np.uint64)
+    r = np.empty(4, dtype=np.uint64)
+    check(lib().zk_sumcheck_round_from_evals(transcript.h, _ptr(evals), evals.shape[0], _ptr(coeffs), _ptr(r)))
+    return coeffs, r
+
+
+def prove_sum2x2_host(transcript: Transcript, tables: np.ndarray):
+    """tables (4, len, 4) on the host -> (coeffs (log2 len, 3, 4), challenges (log2 len, 4)); host only."""
+    tables = np.ascontiguousarray(tables, dtype=np.uint64)
+    ln = tables.shape[1]
+    n = ln.bit_length() - 1
+    coeffs = np.empty((max(n, 1), 3, 4), dtype=np.uint64)
+    ch = np.empty((max(n, 1), 4), dtype=np.uint64)
+    check(lib().zk_sumcheck_prove_sum2x2_host(transcript.h, _ptr(tables), ln, _ptr(coeffs), _ptr(ch)))
+    return coeffs[:n], ch[:n]
+
+
+def generate_round_polys_sum2x2_sharded(shard4, transcript: Transcript, world: int, dist=None, group=None):
+    """generate_round_polys (sumcheck/src/prover.rs:45-155, SumPolynomial branch) for four tables sharded on
+    the variables bound last.  Every rank returns the same (round_polys (n,3,4), challenges (n,4))."""
+    g = world.bit_length() - 1
+    if world != 1 << g:
+        raise ValueError("world size must be a power of two")
+    ln = shard4.local_len()
+    ell = ln.bit_length() - 1
+    if ell < 1:
+        raise ValueError("each rank needs at least 2 local entries per table")
+    n = ell + g
+    coeffs = np.empty((n, 3, 4), dtype=np.uint64)
+    ch = np.empty((n, 4), dtype=np.uint64)
+    buf = shard4.new_buf()
+    shard4.eval(buf)
+    for k in range(ell):
+        evals = gather_sums(buf[:3], world, dist, group)
+        coeffs[k], ch[k] = round_from_evals(transcript, evals)
+        shard4.fold(ch[k], buf)
+    if g:
+        rows = gather_sums(buf[:4], world, dist, group)           # (world, 4 tables, 4 limbs)
+        c, r = prove_sum2x2_host(transcript, rows.transpose(1, 0, 2))
+        coeffs[ell:], ch[ell:] = c, r
+    return coeffs, ch
