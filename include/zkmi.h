@@ -216,8 +216,8 @@ int zk_gkr_prove(zk_ctx *ctx, zk_circuit *circuit, zk_transcript *transcript, co
 /* ---- tuning / measurement hooks (no reference counterpart) ---------------------------- */
 /* Rounds bound per device pass by the single-MLE prover (1..4, default 4) and the fold kernel
  * variant: 0 = inner product with eq weights, one reduction per output (default); 1 = fold tree;
- * 2 = fold tree with register double-buffering; 3 = as 0 with 2-element load groups.  Proof bytes do not
- * depend on either. */
+ * 2 = fold tree with register double-buffering; 3 = as 0 with 2-element load groups; 4 / 5 / 6 = as 0 with a
+ * rolling window of 8 / 4 / 16 element loads in flight per lane.  Proof bytes do not depend on either. */
 int zk_ctx_set_fold_batch(zk_ctx *ctx, int rounds_per_pass, int variant);
 enum { ZK_K_BLOCK_SUMS = 0, ZK_K_MULTIFOLD = 1, ZK_K_FOLD = 2, ZK_K_EVAL3 = 3, ZK_K_FOLD4_EVAL3 = 4, ZK_K_COUNT = 8 };
 /* per-kernel HIP-event timing of the launches made by the provers on this context */

@@ -156,7 +156,8 @@ def test_sumcheck_vs_oracle_random_full_range(ctx, log_n):
     assert ok == O.sumcheck_verify(table, oclaim, ocoeffs)
 
 
-@pytest.mark.parametrize("batch,db", [(1, 0), (1, 1), (1, 2), (2, 0), (2, 1), (2, 2), (2, 3), (3, 0), (3, 1), (3, 2), (3, 3), (4, 0), (4, 1), (4, 3)])
+@pytest.mark.parametrize("batch,db", [(1, 0), (1, 1), (1, 2), (2, 0), (2, 1), (2, 2), (2, 3), (3, 0), (3, 1), (3, 2), (3, 3), (4, 0), (4, 1), (4, 3),
+                                      (3, 4), (3, 5), (4, 4), (4, 5), (4, 6)])
 def test_sumcheck_every_fold_batch_setting_gives_the_same_proof(batch, db):
     """Rounds-per-pass batching is an execution schedule, not a protocol change: proofs are identical."""
     c = zk_amd.Context(0)

@@ -50,6 +50,14 @@ __device__ __forceinline__ void fq_store(fq* p, const fq& a) {
     q[1] = make_uint4(a.v[4], a.v[5], a.v[6], a.v[7]);
 }
 
+// streamed-once output: nontemporal hint (measured +2.5 % on the 16-stream fold pass, profiles/r01_mfbench_*)
+__device__ __forceinline__ void fq_store_stream(fq* p, const fq& a) {
+    u32x4* q = reinterpret_cast<u32x4*>(p);
+    u32x4 lo = {a.v[0], a.v[1], a.v[2], a.v[3]}, hi = {a.v[4], a.v[5], a.v[6], a.v[7]};
+    __builtin_nontemporal_store(lo, q);
+    __builtin_nontemporal_store(hi, q + 1);
+}
+
 // a - p if a >= p else a   (a < 2p)
 __device__ __forceinline__ fq fq_reduce_once(const fq& a) {
     const u32 p[8] = FQ_P_LIMBS;
@@ -169,6 +177,16 @@ __device__ __forceinline__ void fq28_unpack(const fq& a, u32 (&l)[10]) {
 __device__ __forceinline__ void fq28_mac(u64 (&acc)[20], const fq& a, const u32* __restrict__ w) {
     u32 l[10];
     fq28_unpack(a, l);
+#pragma unroll
+    for (int j = 0; j < 10; ++j) {
+        const u32 wj = w[j];
+#pragma unroll
+        for (int i = 0; i < 10; ++i) acc[i + j] += (u64)l[i] * wj;
+    }
+}
+
+// the same with the element already unpacked
+__device__ __forceinline__ void fq28_mac_limbs(u64 (&acc)[20], const u32 (&l)[10], const u32* __restrict__ w) {
 #pragma unroll
     for (int j = 0; j < 10; ++j) {
         const u32 wj = w[j];

@@ -178,7 +178,7 @@ __global__ void __launch_bounds__(kThreads) k_multifold_lazy(const fq* __restric
             for (int k = 0; k < 20; ++k) acc[k] = 0;
             lazy_mac<M, G>(acc, A, W, 0);
             fq o = fq28_redc(acc);
-            fq_store(dst + j0 + i, o);
+            fq_store_stream(dst + j0 + i, o);
             acc1[0] = fq_add(acc1[0], o);
             i = n;
             if (i >= Lb) break;
@@ -188,7 +188,7 @@ __global__ void __launch_bounds__(kThreads) k_multifold_lazy(const fq* __restric
             for (int k = 0; k < 20; ++k) acc[k] = 0;
             lazy_mac<M, G>(acc, B, W, 0);
             o = fq28_redc(acc);
-            fq_store(dst + j0 + i, o);
+            fq_store_stream(dst + j0 + i, o);
             acc1[0] = fq_add(acc1[0], o);
             i = n;
         }
@@ -207,10 +207,62 @@ __global__ void __launch_bounds__(kThreads) k_multifold_lazy(const fq* __restric
                 lazy_mac<M, G>(acc, B, W, g + 1);
             }
             fq o = fq28_redc(acc);
-            fq_store(dst + j0 + i, o);
+            fq_store_stream(dst + j0 + i, o);
             acc1[0] = fq_add(acc1[0], o);
             i = n;
         }
+    }
+    block_sum_store<1>(acc1, partials);
+}
+
+// Rolling-window form of the same inner product: every lane keeps D element loads in flight at all
+// times (slot b % D is refilled with element b + D -- of the next output once b + D >= 2^M -- right after
+// it has been unpacked), so the loads in flight no longer drop to one register buffer while the other is
+// being multiplied, and the window, not 2 x G, sets the register cost.
+// one element of the window, unrolled at the source level (the optimizer re-rolls a #pragma unroll loop here)
+template <int M, int D, int B>
+struct RollStep {
+    static __device__ __forceinline__ void run(fq (&buf)[D], u64 (&acc)[20], const fq* __restrict__ src, size_t Lout, size_t cur, size_t nxt,
+                                               const W28<M>& W) {
+        constexpr int NB = 1 << M;
+        u32 l[10];
+        fq28_unpack(buf[B % D], l);
+        if constexpr (B + D < NB) buf[B % D] = fq_load_stream(src + (size_t)(B + D) * Lout + cur);
+        else buf[B % D] = fq_load_stream(src + (size_t)(B + D - NB) * Lout + nxt);
+        asm volatile("" ::: "memory"); // keep the refill where it is issued
+        fq28_mac_limbs(acc, l, W.w[B]);
+        if constexpr (B + 1 < NB) RollStep<M, D, B + 1>::run(buf, acc, src, Lout, cur, nxt, W);
+    }
+};
+
+template <int M, int D>
+__global__ void __launch_bounds__(kThreads) k_multifold_roll(const fq* __restrict__ src, fq* __restrict__ dst, size_t Lout, W28<M> W,
+                                                              int log_ob, fq* __restrict__ partials) {
+    constexpr int NB = 1 << M;
+    static_assert(NB % D == 0, "window must divide the batch");
+    const unsigned gpb = gridDim.x >> log_ob;
+    const unsigned c = blockIdx.x / gpb, wl = blockIdx.x % gpb;
+    const size_t Lb = Lout >> log_ob;
+    const size_t j0 = (size_t)c * Lb;
+    const size_t stride = (size_t)gpb * kThreads;
+    fq acc1[1] = {fq_zero()};
+    size_t i = (size_t)wl * kThreads + threadIdx.x;
+    fq buf[D];
+    if (i < Lb) {
+#pragma unroll
+        for (int s = 0; s < D; ++s) buf[s] = fq_load_stream(src + (size_t)s * Lout + j0 + i);
+    }
+    while (i < Lb) {
+        const size_t n = i + stride;
+        const size_t nn = n < Lb ? n : i; // past the end: re-read this output's elements (unused) -- keeps the loop branch-free
+        u64 acc[20];
+#pragma unroll
+        for (int k = 0; k < 20; ++k) acc[k] = 0;
+        RollStep<M, D, 0>::run(buf, acc, src, Lout, j0 + i, j0 + nn, W);
+        fq o = fq28_redc(acc);
+        fq_store(dst + j0 + i, o);
+        acc1[0] = fq_add(acc1[0], o);
+        i = n;
     }
     block_sum_store<1>(acc1, partials);
 }
@@ -427,10 +479,31 @@ static int launch_multifold_lazy_m(const void* src, void* dst, size_t Lout, cons
     hipLaunchKernelGGL((k_multifold_lazy<M, G>), dim3(g), dim3(kThreads), 0, st, (const fq*)src, (fq*)dst, Lout, W, log_ob, (fq*)partials);
     return g;
 }
+template <int M, int D>
+static int launch_multifold_roll_m(const void* src, void* dst, size_t Lout, const uint32_t* w28, int log_ob, void* partials, hipStream_t st) {
+    W28<M> W;
+    for (int b = 0; b < (1 << M); ++b)
+        for (int j = 0; j < 10; ++j) W.w[b][j] = w28[b * 10 + j];
+    int g = grid_blocks(Lout >> log_ob, log_ob);
+    hipLaunchKernelGGL((k_multifold_roll<M, D>), dim3(g), dim3(kThreads), 0, st, (const fq*)src, (fq*)dst, Lout, W, log_ob, (fq*)partials);
+    return g;
+}
 int launch_multifold_lazy(int m, int group, const void* src, void* dst, size_t Lout, const uint32_t* w28, int log_ob, void* partials,
                           void* out, hipStream_t st) {
     int g = 0;
     const bool g2 = group == 2;
+    if (group >= 100 && m >= 3) { // rolling window of group - 100 loads
+        const int d = group - 100;
+        if (m == 3) g = d == 4 ? launch_multifold_roll_m<3, 4>(src, dst, Lout, w28, log_ob, partials, st)
+                               : launch_multifold_roll_m<3, 8>(src, dst, Lout, w28, log_ob, partials, st);
+        else if (m == 4) g = d == 4 ? launch_multifold_roll_m<4, 4>(src, dst, Lout, w28, log_ob, partials, st)
+                          : d == 16 ? launch_multifold_roll_m<4, 16>(src, dst, Lout, w28, log_ob, partials, st)
+                                    : launch_multifold_roll_m<4, 8>(src, dst, Lout, w28, log_ob, partials, st);
+        else return -1;
+        hipLaunchKernelGGL(k_reduce_groups, dim3(1 << log_ob), dim3(kThreads), 0, st, (const fq*)partials, g >> log_ob, (fq*)out);
+        return g;
+    }
+    if (group >= 100) group = 4;
     switch (m) {
         case 1: g = launch_multifold_lazy_m<1, 2>(src, dst, Lout, w28, log_ob, partials, st); break;
         case 2: g = g2 ? launch_multifold_lazy_m<2, 2>(src, dst, Lout, w28, log_ob, partials, st)

@@ -769,10 +769,10 @@ int zk_sumcheck_verify_mle(zk_ctx* c, const zk_mle* poly, const uint64_t claim[4
 
 // ---- measurement ----------------------------------------------------------------------------------
 int zk_ctx_set_fold_batch(zk_ctx* c, int rounds_per_pass, int variant) {
-    if (!c || rounds_per_pass < 1 || rounds_per_pass > zkk::kMaxFoldBatch || variant < 0 || variant > 3) return ZK_E_ARG;
+    if (!c || rounds_per_pass < 1 || rounds_per_pass > zkk::kMaxFoldBatch || variant < 0 || variant > 6) return ZK_E_ARG;
     c->fold_batch = rounds_per_pass;
-    c->lazy = variant == 0 || variant == 3;
-    c->lazy_group = variant == 3 ? 2 : 4;
+    c->lazy = variant == 0 || variant >= 3;
+    c->lazy_group = variant == 3 ? 2 : variant == 4 ? 108 : variant == 5 ? 104 : variant == 6 ? 116 : 4;
     c->double_buffer = variant == 2;
     return ZK_OK;
 }
