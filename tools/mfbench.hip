@@ -116,7 +116,10 @@ int main(int argc, char** argv) {
     const int logn = argc > 1 ? atoi(argv[1]) : 28;
     const size_t n = (size_t)1 << logn, Lout = n >> 4;
     fq *src, *dst, *part, *sums;
-    CHK(hipMalloc(&src, n * 32)); CHK(hipMalloc(&dst, n * 32)); // sized for the widest ablation (1 stream: as many outputs as inputs) CHK(hipMalloc(&part, 2048 * 3 * 32)); CHK(hipMalloc(&sums, 16 * 32));
+    CHK(hipMalloc(&src, n * 32));
+    CHK(hipMalloc(&dst, n * 32)); // sized for the widest ablation (1 stream: as many outputs as inputs)
+    CHK(hipMalloc(&part, 2048 * 3 * 32));
+    CHK(hipMalloc(&sums, 16 * 32));
     launch_generate(src, 1, 0, 1, n, 0);
     CHK(hipDeviceSynchronize());
     hipEvent_t a, b; CHK(hipEventCreate(&a)); CHK(hipEventCreate(&b));

@@ -165,6 +165,7 @@ __global__ void __launch_bounds__(kThreads) k_multifold_lazy(const fq* __restric
     const size_t j0 = (size_t)c * Lb;
     const size_t stride = (size_t)gpb * kThreads;
     fq acc1[1] = {fq_zero()};
+    const bool big = Lout >= ((size_t)1 << 22); // outputs beyond the caches: streaming stores; small ones stay cached for the next pass
     size_t i = (size_t)wl * kThreads + threadIdx.x;
     fq A[G], B[G];
     if (i < Lb) lazy_load<G>(A, src, Lout, j0 + i, 0);
@@ -178,7 +179,7 @@ __global__ void __launch_bounds__(kThreads) k_multifold_lazy(const fq* __restric
             for (int k = 0; k < 20; ++k) acc[k] = 0;
             lazy_mac<M, G>(acc, A, W, 0);
             fq o = fq28_redc(acc);
-            fq_store_stream(dst + j0 + i, o);
+            if (big) fq_store_stream(dst + j0 + i, o); else fq_store(dst + j0 + i, o);
             acc1[0] = fq_add(acc1[0], o);
             i = n;
             if (i >= Lb) break;
@@ -188,7 +189,7 @@ __global__ void __launch_bounds__(kThreads) k_multifold_lazy(const fq* __restric
             for (int k = 0; k < 20; ++k) acc[k] = 0;
             lazy_mac<M, G>(acc, B, W, 0);
             o = fq28_redc(acc);
-            fq_store_stream(dst + j0 + i, o);
+            if (big) fq_store_stream(dst + j0 + i, o); else fq_store(dst + j0 + i, o);
             acc1[0] = fq_add(acc1[0], o);
             i = n;
         }
@@ -207,7 +208,7 @@ __global__ void __launch_bounds__(kThreads) k_multifold_lazy(const fq* __restric
                 lazy_mac<M, G>(acc, B, W, g + 1);
             }
             fq o = fq28_redc(acc);
-            fq_store_stream(dst + j0 + i, o);
+            if (big) fq_store_stream(dst + j0 + i, o); else fq_store(dst + j0 + i, o);
             acc1[0] = fq_add(acc1[0], o);
             i = n;
         }

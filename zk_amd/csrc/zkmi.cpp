@@ -51,7 +51,8 @@ static int ctx_create(int device_id, bool own_stream, hipStream_t stream, zk_ctx
         (own_stream && fail(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking), "hipStreamCreate")) ||
         fail(hipMalloc(&c->partials, (size_t)zkk::kMaxBlocks * 3 * kElem), "hipMalloc partials") ||
         fail(hipMalloc(&c->sums_dev, kSums * kElem), "hipMalloc sums") ||
-        fail(hipHostMalloc((void**)&c->sums_host, kSums * kElem, hipHostMallocDefault), "hipHostMalloc sums")) {
+        fail(hipHostMalloc((void**)&c->sums_host, kHostStage * kElem, hipHostMallocMapped), "hipHostMalloc sums") ||
+        fail(hipHostGetDevicePointer(&c->sums_host_dev, c->sums_host, 0), "hipHostGetDevicePointer")) {
         zk_ctx_destroy(c);
         return rc;
     }
@@ -309,10 +310,12 @@ int zk_mle_round_sums(const zk_mle* m, uint64_t out[8]) {
     if (rc) return rc;
     {
         ProfScope ps(c, ZK_K_BLOCK_SUMS, (uint64_t)m->len * 32);
-        zkk::launch_block_sums(m->d, m->len, 1, c->partials, c->sums_dev, c->stream);
+        zkk::launch_block_sums(m->d, m->len, 1, c->partials, c->sums_host_dev, c->stream);
     }
     Fq e[2];
-    if ((rc = fetch_block_sums(c, 2, e))) return rc;
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int s2 = 0; s2 < 2; ++s2) e[s2] = zkh::load(c->sums_host + 4 * s2);
     prof_collect(c);
     zkh::store(out, e[0]);
     zkh::store(out + 4, e[1]);
@@ -470,9 +473,8 @@ int zk_sumcheck_prove_mle(zk_ctx* c, const zk_mle* poly, int absorb_table, zk_tr
     const unsigned M = (unsigned)c->fold_batch;
     zk_shard st{c, poly->d, n, 0};
     unsigned m = std::min(M, st.ell), k = 0;
-    if ((rc = zk_shard_block_sums(&st, (int)m, c->sums_dev))) return rc;
+    if ((rc = zk_shard_block_sums(&st, (int)m, c->sums_host_dev))) return rc; // sums land in pinned host memory
     for (;;) {
-        HIPCHK(c, hipMemcpyAsync(c->sums_host, c->sums_dev, ((size_t)kElem) << m, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         uint64_t rs[4 * zkk::kMaxFoldBatch];
         host_rounds(tr, c->sums_host, 1, m, coeffs_out + 8 * k, rs, nullptr, k == 0 ? claim_out : nullptr);
@@ -480,7 +482,7 @@ int zk_sumcheck_prove_mle(zk_ctx* c, const zk_mle* poly, int absorb_table, zk_tr
         k += m;
         if (st.ell == m) break; // the fully folded table (one entry) is never used by the prover
         const unsigned m_next = std::min(M, st.ell - m);
-        if ((rc = zk_shard_fold(&st, (int)m, rs, (int)m_next, c->sums_dev))) return rc;
+        if ((rc = zk_shard_fold(&st, (int)m, rs, (int)m_next, c->sums_host_dev))) return rc;
         m = m_next;
     }
     prof_collect(c);
@@ -489,6 +491,57 @@ int zk_sumcheck_prove_mle(zk_ctx* c, const zk_mle* poly, int absorb_table, zk_tr
 
 // ---- sumcheck prover: Sum[Prod[t0,t1], Prod[t2,t3]] ---------------------------------------------
 } // extern "C"
+
+namespace {
+// one round of the SumPolynomial branch from the three evaluations (prover.rs:102-107, :126-135);
+// interpolate([0,1,2], ev) in closed form -- dense_coefficient_form.rs:52-88 gives the same canonical
+// coefficients: c0 = ev0, c2 = (ev0 - 2 ev1 + ev2)/2, c1 = ev1 - ev0 - c2
+Fq host_round_deg2(zk_transcript* tr, const Fq ev[3], uint64_t* coeffs_out) {
+    const Fq inv2 = zkh::inv2();
+    Fq claimed = zkh::add(ev[0], ev[1]);
+    Fq c2 = zkh::mul(zkh::add(zkh::sub(ev[0], zkh::add(ev[1], ev[1])), ev[2]), inv2);
+    Fq c1 = zkh::sub(zkh::sub(ev[1], ev[0]), c2);
+    tr->append_fq(claimed);
+    tr->append_fq(ev[0]);
+    tr->append_fq(c1);
+    tr->append_fq(c2);
+    zkh::store(coeffs_out, ev[0]);
+    zkh::store(coeffs_out + 4, c1);
+    zkh::store(coeffs_out + 8, c2);
+    return tr->sample();
+}
+
+// all log2(len) rounds of the SumPolynomial branch on four host tables T[q*len + j]; final_out (optional):
+// the four tables folded at every challenge
+void host_sum2x2_rounds(zk_transcript* tr, std::vector<Fq>& T, size_t len, uint64_t* coeffs_out, uint64_t* challenges_out,
+                        uint64_t* final_out) {
+    const unsigned n = ilog2(len);
+    size_t cur = len;
+    for (unsigned k = 0; k < n; ++k) {
+        const size_t half = cur / 2;
+        Fq ev[3] = {zkh::zero(), zkh::zero(), zkh::zero()};
+        for (size_t j = 0; j < half; ++j) {
+            Fq lo[4], hi[4], x2[4];
+            for (int q = 0; q < 4; ++q) {
+                lo[q] = T[q * len + j];
+                hi[q] = T[q * len + half + j];
+                x2[q] = zkh::sub(zkh::add(hi[q], hi[q]), lo[q]); // lo + 2 (hi - lo)
+            }
+            ev[0] = zkh::add(ev[0], zkh::add(zkh::mul(lo[0], lo[1]), zkh::mul(lo[2], lo[3])));
+            ev[1] = zkh::add(ev[1], zkh::add(zkh::mul(hi[0], hi[1]), zkh::mul(hi[2], hi[3])));
+            ev[2] = zkh::add(ev[2], zkh::add(zkh::mul(x2[0], x2[1]), zkh::mul(x2[2], x2[3])));
+        }
+        const Fq r = host_round_deg2(tr, ev, coeffs_out + 12 * k);
+        if (challenges_out) zkh::store(challenges_out + 4 * k, r);
+        for (int q = 0; q < 4; ++q)
+            for (size_t j = 0; j < half; ++j)
+                T[q * len + j] = zkh::add(T[q * len + j], zkh::mul(zkh::sub(T[q * len + half + j], T[q * len + j]), r));
+        cur = half;
+    }
+    if (final_out)
+        for (int q = 0; q < 4; ++q) zkh::store(final_out + 4 * q, T[q * len]);
+}
+} // namespace
 
 // the round loop of the SumPolynomial branch on four device tables of `len` entries each;
 // final_out (optional, 4 elements): every table folded at ALL n challenges (the reference's
@@ -519,28 +572,29 @@ int zki::prove_sum2x2_dev(zk_ctx* c, const void* const tables[4], size_t len, zk
     size_t curlen = len;
     Fq ev[3];
     int g;
-    {
-        ProfScope ps(c, ZK_K_EVAL3, (uint64_t)len * 32 * 4);
-        g = zkk::launch_eval3(cur, len / 2, c->partials, c->stream);
-    }
-    HIPCHK(c, hipGetLastError());
-    if ((rc = fetch_sums(c, g, 3, ev))) return rc;
-
-    const Fq inv2 = zkh::inv2();
     for (unsigned k = 0; k < n; ++k) {
-        // interpolate([0,1,2], ev) in closed form (dense_coefficient_form.rs:52-88 gives the same
-        // canonical coefficients): c0 = ev0, c2 = (ev0 - 2 ev1 + ev2)/2, c1 = ev1 - ev0 - c2
-        Fq claimed = zkh::add(ev[0], ev[1]); // prover.rs:102
-        Fq c2 = zkh::mul(zkh::add(zkh::sub(ev[0], zkh::add(ev[1], ev[1])), ev[2]), inv2);
-        Fq c1 = zkh::sub(zkh::sub(ev[1], ev[0]), c2);
-        tr->append_fq(claimed); // :126-129
-        tr->append_fq(ev[0]);
-        tr->append_fq(c1);
-        tr->append_fq(c2);
-        Fq r = tr->sample(); // :132-135
-        zkh::store(coeffs_out + 12 * k, ev[0]);
-        zkh::store(coeffs_out + 12 * k + 4, c1);
-        zkh::store(coeffs_out + 12 * k + 8, c2);
+        if (curlen <= kHostTail && curlen >= 2) {
+            // small tables: one D2H of the four tables, the remaining rounds (and the last fold) on the host --
+            // a round on the device costs a launch, a second stage and a sync whatever the size
+            for (int t = 0; t < 4; ++t)
+                HIPCHK(c, hipMemcpyAsync(c->sums_host + 4 * (size_t)t * curlen, cur[t], curlen * kElem, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            std::vector<Fq> T(4 * curlen);
+            for (size_t i = 0; i < 4 * curlen; ++i) T[i] = zkh::load(c->sums_host + 4 * i);
+            host_sum2x2_rounds(tr, T, curlen, coeffs_out + 12 * k, challenges_out ? challenges_out + 4 * k : nullptr, final_out);
+            break;
+        }
+        if (k == 0) { // first round's evaluations; later rounds get theirs from the fused fold
+            {
+                ProfScope ps(c, ZK_K_EVAL3, (uint64_t)len * 32 * 4);
+                g = zkk::launch_eval3(cur, len / 2, c->partials, c->stream);
+            }
+            HIPCHK(c, hipGetLastError());
+            if ((rc = fetch_sums(c, g, 3, ev))) return rc;
+        }
+        // interpolate([0,1,2], ev) in closed form (dense_coefficient_form.rs:52-88 gives the same canonical
+        // coefficients): host_round_deg2
+        Fq r = host_round_deg2(tr, ev, coeffs_out + 12 * k); // prover.rs:102-107, :126-135
         if (challenges_out) zkh::store(challenges_out + 4 * k, r);
         if (k + 1 == n) {
             if (final_out) { // the last fold, on the host: every table is down to two entries
@@ -585,24 +639,6 @@ int zk_sumcheck_prove_sum2x2(zk_ctx* c, zk_mle* const tables[4], const uint64_t 
 }
 
 // ---- degree-2 prover in steps (sharded tables) ---------------------------------------------------
-namespace {
-// one round of the SumPolynomial branch from the three evaluations (prover.rs:102-107, :126-135)
-Fq host_round_deg2(zk_transcript* tr, const Fq ev[3], uint64_t* coeffs_out) {
-    const Fq inv2 = zkh::inv2();
-    Fq claimed = zkh::add(ev[0], ev[1]);
-    Fq c2 = zkh::mul(zkh::add(zkh::sub(ev[0], zkh::add(ev[1], ev[1])), ev[2]), inv2);
-    Fq c1 = zkh::sub(zkh::sub(ev[1], ev[0]), c2);
-    tr->append_fq(claimed);
-    tr->append_fq(ev[0]);
-    tr->append_fq(c1);
-    tr->append_fq(c2);
-    zkh::store(coeffs_out, ev[0]);
-    zkh::store(coeffs_out + 4, c1);
-    zkh::store(coeffs_out + 8, c2);
-    return tr->sample();
-}
-} // namespace
-
 struct zk_shard4 {
     zk_ctx* ctx;
     const void* cur[4];
@@ -629,28 +665,7 @@ int zk_sumcheck_prove_sum2x2_host(zk_transcript* t, const uint64_t* tables, size
     if (n && !coeffs_out) return ZK_E_ARG;
     std::vector<Fq> T(4 * len);
     for (size_t i = 0; i < 4 * len; ++i) T[i] = zkh::load(tables + 4 * i);
-    size_t cur = len;
-    for (unsigned k = 0; k < n; ++k) {
-        const size_t half = cur / 2;
-        Fq ev[3] = {zkh::zero(), zkh::zero(), zkh::zero()};
-        for (size_t j = 0; j < half; ++j) {
-            Fq lo[4], hi[4], x2[4];
-            for (int q = 0; q < 4; ++q) {
-                lo[q] = T[q * len + j];
-                hi[q] = T[q * len + half + j];
-                x2[q] = zkh::sub(zkh::add(hi[q], hi[q]), lo[q]); // lo + 2 (hi - lo)
-            }
-            ev[0] = zkh::add(ev[0], zkh::add(zkh::mul(lo[0], lo[1]), zkh::mul(lo[2], lo[3])));
-            ev[1] = zkh::add(ev[1], zkh::add(zkh::mul(hi[0], hi[1]), zkh::mul(hi[2], hi[3])));
-            ev[2] = zkh::add(ev[2], zkh::add(zkh::mul(x2[0], x2[1]), zkh::mul(x2[2], x2[3])));
-        }
-        const Fq r = host_round_deg2(t, ev, coeffs_out + 12 * k);
-        if (challenges_out) zkh::store(challenges_out + 4 * k, r);
-        for (int q = 0; q < 4; ++q)
-            for (size_t j = 0; j < half; ++j)
-                T[q * len + j] = zkh::add(T[q * len + j], zkh::mul(zkh::sub(T[q * len + half + j], T[q * len + j]), r));
-        cur = half;
-    }
+    host_sum2x2_rounds(t, T, len, coeffs_out, challenges_out, nullptr);
     return ZK_OK;
 }
 

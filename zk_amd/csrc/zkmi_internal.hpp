@@ -23,6 +23,8 @@ namespace zki {
 constexpr size_t kElem = 32;
 constexpr size_t kChunkElems = (size_t)1 << 21; // 64 MiB staging chunks for byte conversion
 constexpr size_t kSums = 16;                    // 2^kMaxFoldBatch block sums per pass
+constexpr size_t kHostTail = 64;                // degree-2 prover: tables of <= this many entries are finished on the host
+constexpr size_t kHostStage = 4 * kHostTail;    // elements of the pinned staging buffer
 
 inline bool is_pow2(size_t n) { return n && !(n & (n - 1)); }
 inline unsigned ilog2(size_t n) {
@@ -57,7 +59,8 @@ struct zk_ctx {
     bool own_stream = true;     // false: the caller's stream (zk_ctx_create_on_stream)
     void* partials = nullptr;   // kMaxBlocks * 3 elements
     void* sums_dev = nullptr;   // kSums elements
-    uint64_t* sums_host = nullptr; // pinned, kSums elements
+    uint64_t* sums_host = nullptr; // pinned + device-mapped, kHostStage elements: kernels write small results here directly
+    void* sums_host_dev = nullptr; // the device address of sums_host
     int fold_batch = 4;          // rounds bound per device pass (1..kMaxFoldBatch)
     bool double_buffer = false;  // register double-buffering in k_multifold (tree variant)
     bool lazy = true;            // inner-product form with one reduction per output (k_multifold_lazy)
@@ -148,9 +151,9 @@ inline void prof_collect(zk_ctx* c) {
 
 // second stage + device->host of ns sums; blocks until they are on the host
 inline int fetch_sums(zk_ctx* c, int nblocks, int ns, Fq* out) {
-    zkk::launch_reduce_partials(c->partials, nblocks, ns, c->sums_dev, c->stream);
+    // the second stage stores straight into the device-mapped pinned buffer: no copy command, one sync
+    zkk::launch_reduce_partials(c->partials, nblocks, ns, c->sums_host_dev, c->stream);
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpyAsync(c->sums_host, c->sums_dev, (size_t)ns * kElem, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     for (int s = 0; s < ns; ++s) out[s] = zkh::load(c->sums_host + 4 * s);
     return ZK_OK;
