@@ -272,11 +272,37 @@ int zk_mle_partially_evaluate(const zk_mle* m, size_t var, const uint64_t r[4], 
 int zk_mle_evaluate(const zk_mle* m, const uint8_t* has, const uint64_t* vals, size_t npts, zk_mle** out) {
     if (!m || !out || (npts && (!has || !vals))) return ZK_E_ARG;
     if (npts != ilog2(m->len)) return ZK_E_POINTS_LEN; // evaluation_form.rs:197-199
-    zk_mle* acc = nullptr;
-    int rc = zk_mle_clone(m, &acc); // MultiLinearPolynomial::new(&self.evaluation_points), :204
+    zk_ctx* c = m->ctx;
+    int rc = set_device(c);
     if (rc) return rc;
-    size_t done = 0;
-    for (size_t idx = 0; idx < npts; ++idx) {
+    // A leading run of Some(..) binds the TOP variables one after the other (:206-217 with idx - done = 0
+    // each time): the batched fold pass of the prover does up to kMaxFoldBatch of them per sweep.  This is
+    // the verifier's oracle check (verifier.rs:15-26) and GKR's W(r) evaluations (gkr/src/prover.rs:70-75).
+    size_t pre = 0;
+    while (pre < npts && has[pre]) ++pre;
+    zk_mle* acc = nullptr;
+    size_t first = 0;
+    if (pre >= 2) {
+        zk_shard st{c, m->d, (unsigned)npts, 0};
+        while (first < pre) {
+            const int mm = (int)std::min<size_t>(zkk::kMaxFoldBatch, pre - first);
+            if ((rc = zk_shard_fold(&st, mm, vals + 4 * first, 0, nullptr))) return rc;
+            first += (size_t)mm;
+        }
+        if ((rc = new_mle(c, (size_t)1 << st.ell, &acc))) return rc;
+        hipError_t e = hipMemcpyAsync(acc->d, st.cur, acc->len * kElem, hipMemcpyDeviceToDevice, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) {
+            c->err = std::string("evaluate: ") + hipGetErrorString(e);
+            zk_mle_free(acc);
+            return ZK_E_HIP;
+        }
+        prof_collect(c);
+    } else {
+        if ((rc = zk_mle_clone(m, &acc))) return rc; // MultiLinearPolynomial::new(&self.evaluation_points), :204
+    }
+    size_t done = first;
+    for (size_t idx = first; idx < npts; ++idx) {
         if (!has[idx]) continue;
         zk_mle* next = nullptr;
         rc = zk_mle_partially_evaluate(acc, idx - done, vals + 4 * idx, &next); // :208
@@ -376,12 +402,6 @@ void host_rounds(zk_transcript* tr, const uint64_t* sums, int world, unsigned m,
 }
 } // namespace
 
-struct zk_shard {
-    zk_ctx* ctx;
-    const void* cur; // current local table
-    unsigned ell;    // variables left in it
-    int pass;
-};
 
 int zk_sumcheck_rounds_from_block_sums(zk_transcript* t, const uint64_t* sums, int world, int m, uint64_t* coeffs_out,
                                        uint64_t* challenges_out, uint64_t* folded_out, uint64_t total_out[4]) {

@@ -85,6 +85,14 @@ struct zk_mle {
     int device; // copy of ctx->device: freeing a table must not touch a context that is already gone
 };
 
+// a table being folded from the top: the single-GPU prover, a rank's shard, evaluate()
+struct zk_shard {
+    zk_ctx* ctx;
+    const void* cur; // current local table
+    unsigned ell;    // variables left in it
+    int pass;
+};
+
 #define HIPCHK(ctx, call)                                                                           \
     do {                                                                                            \
         hipError_t e_ = (call);                                                                     \
