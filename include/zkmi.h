@@ -213,6 +213,13 @@ int zk_gkr_prove(zk_ctx *ctx, zk_circuit *circuit, zk_transcript *transcript, co
                  uint64_t *output_poly_out, uint64_t *w_evals_out, uint64_t *claims_out, uint64_t *coeffs_out,
                  double *layer_ms_out);
 
+/* GKRVerifier::verify_proof (gkr/src/verifier.rs:21-119); proof arrays as zk_gkr_prove returns them.  The
+ * predicates are evaluated from the gate list (the reference rebuilds the dense tables, :39-40).  *ok_out =
+ * 1 accepted, 0 rejected. */
+int zk_gkr_verify(zk_ctx *ctx, zk_circuit *circuit, zk_transcript *transcript, const zk_mle *inputs,
+                  const uint64_t *output_poly, size_t output_len, const uint64_t *w_evals, const uint64_t *claims,
+                  const uint64_t *coeffs, int *ok_out);
+
 /* ---- tuning / measurement hooks (no reference counterpart) ---------------------------- */
 /* Rounds bound per device pass by the single-MLE prover (1..4, default 4) and the fold kernel
  * variant: 0 = inner product with eq weights, one reduction per output (default); 1 = fold tree;

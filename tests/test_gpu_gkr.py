@@ -10,7 +10,7 @@ import pytest
 
 import oracle_lib as O
 import zk_amd
-from zk_amd import Circuit, Gate, GKRProver, Operation
+from zk_amd import Circuit, Gate, GKRProver, GKRVerifier, Operation
 
 pytestmark = pytest.mark.gpu
 SEED = 0x5EED0000
@@ -156,3 +156,54 @@ def test_wide_circuit_selfconsistent():
         ok, final, ch = zk_amd.SumcheckVerifier.partial_verify(p, vt)
         assert ok, f"layer {i}"
     assert vt.peek_digest() == tr.peek_digest()
+
+
+# ---------------------------------------------------------------- verifier (gkr/src/verifier.rs:21-119)
+def test_verifier_accepts_and_rejects_like_the_oracle():        # gkr_protocol.rs:126-142
+    ctx = zk_amd.default_context()
+    for layers, inputs in ((CIRCUIT_GKR, O.ints_to_mont([1, 2, 3, 4, 5, 6, 7, 8])),
+                           (random_circuit([16, 8, 8, 3], 2), O.gen_table(SEED + 2, 0, 16)),
+                           (random_circuit([2, 2, 2], 5), O.gen_table(SEED + 5, 0, 2))):
+        circuit, oc = mk(layers, ctx), O.OCircuit(layers)
+        tr = zk_amd.Transcript()
+        proof = GKRProver.generate_proof(circuit, tr, inputs)
+        vt = zk_amd.Transcript()
+        assert GKRVerifier.verify_proof(inputs, circuit, vt, proof)
+        ovt = O.OTranscript()
+        assert O.gkr_verify(inputs, oc, ovt, O.gkr_prove(oc, O.OTranscript(), inputs))
+        assert vt.peek_digest() == ovt.peek_digest()          # the verifier's transcript ends where the oracle verifier's does
+        # wrong inputs
+        bad_in = inputs.copy()
+        bad_in[0] = O.fq1(12345)
+        assert not GKRVerifier.verify_proof(bad_in, circuit, zk_amd.Transcript(), proof)
+        assert not O.gkr_verify(bad_in, oc, O.OTranscript(), O.gkr_prove(oc, O.OTranscript(), inputs))
+        # a coefficient of the LAST round of a layer (earlier rounds make the reference panic rather than return false)
+        bad = GKRProver.generate_proof(circuit, zk_amd.Transcript(), inputs)
+        bad.sumcheck_proofs[0].round_polys[-1, 0] = O.fq1(7)
+        assert not GKRVerifier.verify_proof(inputs, circuit, zk_amd.Transcript(), bad)
+        # an earlier round
+        bad = GKRProver.generate_proof(circuit, zk_amd.Transcript(), inputs)
+        bad.sumcheck_proofs[-1].round_polys[0, 1] = O.fq1(7)
+        assert not GKRVerifier.verify_proof(inputs, circuit, zk_amd.Transcript(), bad)
+        # a W evaluation sent by the prover
+        if proof.w_polys_evals:
+            bad = GKRProver.generate_proof(circuit, zk_amd.Transcript(), inputs)
+            bad.w_polys_evals[0] = (O.fq1(3), bad.w_polys_evals[0][1])
+            assert not GKRVerifier.verify_proof(inputs, circuit, zk_amd.Transcript(), bad)
+        # the claim of a layer
+        bad = GKRProver.generate_proof(circuit, zk_amd.Transcript(), inputs)
+        bad.sumcheck_proofs[0].initial_claim_sum = O.fq1(1)
+        assert not GKRVerifier.verify_proof(inputs, circuit, zk_amd.Transcript(), bad)
+
+
+def test_verifier_on_a_wide_circuit():
+    ctx = zk_amd.default_context()
+    W, depth = 1 << 12, 3
+    rng = random.Random(9)
+    layers = [[((2 * g) % W, (2 * g + 1) % W, rng.randrange(2)) for g in range(W)] for _ in range(depth)]
+    circuit = mk(layers, ctx)
+    inputs = O.gen_table(SEED + 99, 0, W)
+    proof = GKRProver.generate_proof(circuit, zk_amd.Transcript(), inputs)
+    assert GKRVerifier.verify_proof(inputs, circuit, zk_amd.Transcript(), proof)
+    proof.sumcheck_proofs[1].round_polys[-1, 2] = O.fq1(99)
+    assert not GKRVerifier.verify_proof(inputs, circuit, zk_amd.Transcript(), proof)

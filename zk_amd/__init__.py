@@ -7,12 +7,12 @@ calls raise.
 from ._lib import LIB_PATH, SYMBOLS, ZkError, lib
 from .circuit import Circuit, Gate, Operation
 from .context import Context, default_context
-from .gkr import GKRProof, GKRProver
+from .gkr import GKRProof, GKRProver, GKRVerifier
 from .polynomials import MultiLinearPolynomial, ProductPolynomial, SumPolynomial
 from .sumcheck import SumCheckProof, SumcheckProver, SumcheckVerifier
 from .transcript import Transcript
 
 __all__ = [
     "LIB_PATH", "SYMBOLS", "ZkError", "lib", "Context", "default_context", "MultiLinearPolynomial",
-    "ProductPolynomial", "SumPolynomial", "Circuit", "Gate", "Operation", "GKRProof", "GKRProver", "SumCheckProof", "SumcheckProver", "SumcheckVerifier", "Transcript",
+    "ProductPolynomial", "SumPolynomial", "Circuit", "Gate", "Operation", "GKRProof", "GKRProver", "GKRVerifier", "SumCheckProof", "SumcheckProver", "SumcheckVerifier", "Transcript",
 ]

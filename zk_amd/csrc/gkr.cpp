@@ -376,4 +376,93 @@ int zk_gkr_prove(zk_ctx* c, zk_circuit* ci, zk_transcript* tr, const zk_mle* inp
     return ZK_OK;
 }
 
+// ---- GKRVerifier::verify_proof (gkr/src/verifier.rs:21-119) --------------------------------------
+// Same transcript stream as the prover.  The reference rebuilds the dense predicates and evaluates them at
+// the sumcheck's challenges (:39-73); here add'(u,v), mul'(u,v) come from the gate list
+// (k_gkr_pred_eval).  Like the reference, the layer-0 claim is taken from the proof, not recomputed from
+// output_poly (:63-64).  A sumcheck round that fails makes the reference panic in evaluate() on the short
+// challenge vector (evaluation_form.rs:197-199) unless it is the last round; both are reported as ok = 0.
+int zk_gkr_verify(zk_ctx* c, zk_circuit* ci, zk_transcript* tr, const zk_mle* inputs, const uint64_t* output_poly, size_t output_len,
+                  const uint64_t* w_evals, const uint64_t* claims, const uint64_t* coeffs, int* ok_out) {
+    if (!c || !ci || !tr || !inputs || !output_poly || !claims || !coeffs || !ok_out || ci->ctx != c || inputs->ctx != c) return ZK_E_ARG;
+    *ok_out = 0;
+    const size_t L = ci->layers.size();
+    if (L == 0) return ZK_E_LAYER_OOB;
+    if (L > 1 && !w_evals) return ZK_E_ARG;
+    if (!is_pow2(output_len)) return ZK_E_NOT_POW2;
+    int rc = set_device(c);
+    if (rc) return rc;
+
+    size_t max_in = 2, max_out = std::max<size_t>(2, output_len);
+    for (const LayerDev& Ly : ci->layers) {
+        max_in = std::max(max_in, (size_t)1 << Ly.k_in);
+        max_out = std::max(max_out, Ly.n_out);
+    }
+    const size_t eq_half = std::min((size_t)1 << zkk::kMaxEqVars, std::max(max_in, max_out));
+    DevBuf buf;
+    HIPCHK(c, hipMalloc(&buf.p, (max_out + 2 * max_in + 4 * eq_half) * kElem));
+    uint8_t* base = (uint8_t*)buf.p;
+    auto take = [&](size_t n) { void* p = base; base += n * kElem; return p; };
+    void *wt = take(max_out), *Eu = take(max_in), *Ev = take(max_in);
+    void* eqs[4] = {take(eq_half), take(eq_half), take(eq_half), take(eq_half)};
+
+    for (size_t i = 0; i < output_len; ++i) tr->append_fq(zkh::load(output_poly + 4 * i)); // :30
+    const unsigned k0 = ilog2(output_len);
+    std::vector<uint64_t> rnd(4 * std::max<size_t>(k0, 1));
+    for (unsigned i = 0; i < k0; ++i) zkh::store(&rnd[4 * i], tr->sample()); // :32-36
+    size_t n_rnd = k0, coeff_off = 0;
+
+    for (size_t layer_idx = 0; layer_idx < L; ++layer_idx) {
+        const LayerDev& Ly = ci->layers[L - 1 - layer_idx];
+        const int k_in = Ly.k_in, k_out = Ly.k_out;
+        const size_t n_in = (size_t)1 << k_in, rounds = 2 * (size_t)k_in;
+        if (layer_idx == 0) {
+            if (n_rnd != (size_t)k_out) return ZK_OK; // a proof whose output_poly does not fit the circuit: rejected
+            build_eq(c, wt, k_out, rnd.data(), zkh::one(), eqs[0], eqs[1]); // :43
+        } else {
+            if (n_rnd != 2 * (size_t)k_out) return ZK_E_LEN_MISMATCH; // the circuit's layers do not chain (the prover refuses it too)
+            const Fq alpha = tr->sample(), beta = tr->sample(); // :45-46
+            build_eq2(c, wt, k_out, rnd.data(), alpha, rnd.data() + 4 * k_out, beta, eqs); // :49-56
+        }
+        int ok = 0;
+        uint64_t final_claim[4];
+        std::vector<uint64_t> ch(4 * std::max<size_t>(rounds, 1));
+        if ((rc = zk_sumcheck_partial_verify(claims + 4 * layer_idx, coeffs + 12 * coeff_off, rounds, 3, tr, &ok, final_claim, ch.data()))) return rc; // :63-64
+        if (!ok) return ZK_OK;
+        // add'(u,v), mul'(u,v) :67-73
+        build_eq(c, Eu, k_in, ch.data(), zkh::one(), eqs[0], eqs[1]);
+        build_eq(c, Ev, k_in, ch.data() + 4 * k_in, zkh::one(), eqs[2], eqs[3]);
+        const int g = zkk::launch_gkr_pred_eval(Ly.left, Ly.right, Ly.op, wt, Eu, Ev, Ly.n_gates, c->partials, c->stream);
+        HIPCHK(c, hipGetLastError());
+        Fq pe[2];
+        if ((rc = fetch_sums(c, g, 2, pe))) return rc;
+        Fq wb, wc;
+        if (layer_idx + 1 == L) { // the input layer: W from the inputs themselves, :76-94
+            if (inputs->len != n_in) return ZK_E_POINTS_LEN; // evaluate() panics on the length mismatch
+            std::vector<uint8_t> has(k_in, 1);
+            for (int side = 0; side < 2; ++side) {
+                zk_mle* e = nullptr;
+                if ((rc = zk_mle_evaluate(inputs, has.data(), ch.data() + 4 * (size_t)side * k_in, (size_t)k_in, &e))) return rc;
+                uint64_t v[4];
+                rc = zk_mle_download_mont(e, v);
+                zk_mle_free(e);
+                if (rc) return rc;
+                (side ? wc : wb) = zkh::load(v);
+            }
+        } else { // :96-98
+            wb = zkh::load(w_evals + 8 * layer_idx);
+            wc = zkh::load(w_evals + 8 * layer_idx + 4);
+        }
+        tr->append_fq(wb); // :101-104
+        tr->append_fq(wc);
+        const Fq fbc = zkh::add(zkh::mul(pe[0], zkh::add(wb, wc)), zkh::mul(pe[1], zkh::mul(wb, wc))); // :106-107
+        if (fbc != zkh::load(final_claim)) return ZK_OK; // :111-113
+        rnd = ch;
+        n_rnd = rounds;
+        coeff_off += rounds;
+    }
+    *ok_out = 1;
+    return ZK_OK;
+}
+
 } // extern "C"

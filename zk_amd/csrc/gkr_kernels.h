@@ -32,6 +32,9 @@ void launch_gkr_phase1(void* A, void* H2, const uint32_t* lptr, const uint32_t* 
 void launch_gkr_phase2(void* T0, void* T2, void* T3, const uint32_t* rptr, const uint32_t* ridx, const uint32_t* left,
                        const uint8_t* op, const void* wt, const void* Eu, const void* W, const uint64_t wu[4], size_t n_c,
                        hipStream_t st);
+// verifier: per-block shares (2 per block: add, mul) of sum_g wt[o_g] eq(u,l_g) eq(v,r_g); returns the block count (<= 1024)
+int launch_gkr_pred_eval(const uint32_t* left, const uint32_t* right, const uint8_t* op, const void* wt, const void* Eu, const void* Ev,
+                         size_t n_gates, void* partials, hipStream_t st);
 // the reference's dense tables (small circuits / API parity)
 // get_gate_poly (circuit.rs:82-123): out has n_out << 2*k_in entries, zero except 1 at (o << 2k_in | l << k_in | r)
 void launch_gate_poly(void* out, size_t n_total, const uint32_t* left, const uint32_t* right, const uint8_t* op, size_t n_gates,

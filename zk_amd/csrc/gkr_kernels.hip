@@ -120,6 +120,35 @@ __global__ void __launch_bounds__(kT) k_gkr_phase2(fq* __restrict__ T0, fq* __re
     }
 }
 
+// verifier side: add'(u,v) and mul'(u,v) from the gate list, sum_g wt[o_g] * eq(u, l_g) * eq(v, r_g) split by gate type
+// (what `new_addi_b_c.evaluate(&next_evaluation_values)` yields on the dense tables, gkr/src/verifier.rs:67-73).
+// partials[2*block + 0] = add share, [2*block + 1] = mul share
+__global__ void __launch_bounds__(kT) k_gkr_pred_eval(const u32* __restrict__ left, const u32* __restrict__ right, const uint8_t* __restrict__ op,
+                                                      const fq* __restrict__ wt, const fq* __restrict__ Eu, const fq* __restrict__ Ev, size_t n_gates,
+                                                      fq* __restrict__ partials) {
+    fq acc[2] = {fq_zero(), fq_zero()};
+    const size_t stride = (size_t)gridDim.x * kT;
+    for (size_t g = (size_t)blockIdx.x * kT + threadIdx.x; g < n_gates; g += stride) {
+        const fq t = fq_mul(fq_mul(fq_load(wt + g), fq_load(Eu + left[g])), fq_load(Ev + right[g]));
+        if (op[g]) acc[1] = fq_add(acc[1], t);
+        else acc[0] = fq_add(acc[0], t);
+    }
+    __shared__ fq lds[2][kT / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        fq w = fq_wave_sum(acc[s]);
+        if (lane == 0) lds[s][wave] = w;
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        fq t = lds[threadIdx.x][0];
+#pragma unroll
+        for (int w = 1; w < kT / 64; ++w) t = fq_add(t, lds[threadIdx.x][w]);
+        fq_store(partials + (size_t)blockIdx.x * 2 + threadIdx.x, t);
+    }
+}
+
 __global__ void __launch_bounds__(kT) k_gate_poly(fq* __restrict__ out, const u32* __restrict__ left, const u32* __restrict__ right,
                                                   const uint8_t* __restrict__ op, size_t n_gates, int k_in, int want_op) {
     const fq one = fq_one_mont();
@@ -171,6 +200,14 @@ void launch_gkr_phase2(void* T0, void* T2, void* T3, const uint32_t* rptr, const
                        const void* wt, const void* Eu, const void* W, const uint64_t wu[4], size_t n_c, hipStream_t st) {
     hipLaunchKernelGGL(k_gkr_phase2, dim3(grid1d(n_c)), dim3(kT), 0, st, (fq*)T0, (fq*)T2, (fq*)T3, rptr, ridx, left, op, (const fq*)wt,
                        (const fq*)Eu, (const fq*)W, to_fq4(wu), n_c);
+}
+int launch_gkr_pred_eval(const uint32_t* left, const uint32_t* right, const uint8_t* op, const void* wt, const void* Eu, const void* Ev,
+                         size_t n_gates, void* partials, hipStream_t st) {
+    int g = grid1d(n_gates);
+    if (g > 1024) g = 1024;
+    hipLaunchKernelGGL(k_gkr_pred_eval, dim3(g), dim3(kT), 0, st, left, right, op, (const fq*)wt, (const fq*)Eu, (const fq*)Ev, n_gates,
+                       (fq*)partials);
+    return g;
 }
 void launch_gate_poly(void* out, size_t n_total, const uint32_t* left, const uint32_t* right, const uint8_t* op, size_t n_gates, int k_in,
                       int want_op, hipStream_t st) {

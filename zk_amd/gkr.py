@@ -108,3 +108,27 @@ class GKRProver:
             running = next_w
             proofs.append(proof)
         return GKRProof(Circuit.get_w_i(0, evals).get_evaluation_points(), w_polys_evals, proofs)
+
+
+class GKRVerifier:
+    @staticmethod
+    def verify_proof(initial_inputs, circuit: Circuit, transcript: Transcript, proof: GKRProof) -> bool:
+        """gkr/src/verifier.rs:21-119 (zk_gkr_verify): predicates evaluated from the gate lists on the device."""
+        ctx = circuit.ctx
+        if not isinstance(initial_inputs, MultiLinearPolynomial):
+            initial_inputs = MultiLinearPolynomial(initial_inputs, ctx=ctx)
+        n_layers = circuit.get_layer_count()
+        output = np.ascontiguousarray(proof.output_poly, dtype=np.uint64).reshape(-1, 4)
+        w = np.zeros((max(n_layers - 1, 1), 2, 4), dtype=np.uint64)
+        for i, (wb, wc) in enumerate(proof.w_polys_evals[: n_layers - 1]):
+            w[i, 0], w[i, 1] = wb, wc
+        claims = np.ascontiguousarray(np.stack([p.initial_claim_sum for p in proof.sumcheck_proofs]), dtype=np.uint64)
+        _, rounds = circuit.shape()
+        if len(proof.sumcheck_proofs) != n_layers or [p.round_polys.shape[0] for p in proof.sumcheck_proofs] != rounds:
+            return False
+        coeffs = np.ascontiguousarray(np.concatenate([np.asarray(p.round_polys).reshape(-1, 3, 4) for p in proof.sumcheck_proofs]),
+                                      dtype=np.uint64)
+        ok = C.c_int(0)
+        check(lib().zk_gkr_verify(ctx.h, circuit.h, transcript.h, initial_inputs.h, output.ctypes.data_as(u64p), output.shape[0],
+                                  w.ctypes.data_as(u64p), claims.ctypes.data_as(u64p), coeffs.ctypes.data_as(u64p), C.byref(ok)), ctx.h)
+        return bool(ok.value)
