@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--weak", action="store_true", help="multi-GPU: 2^log_n entries PER GPU instead of in total")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for the multi-GPU exchange")
     ap.add_argument("--shared-device", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
+    ap.add_argument("--force-sharded", action="store_true", help="run the multi-GPU code path (torch.distributed exchange) even with one rank")
     return ap.parse_args()
 
 
@@ -84,6 +85,13 @@ def cpu_baseline(log_n: int):
 
 def main():
     args = parse()
+    # stdout carries exactly ONE JSON line: libraries (RCCL prints a version banner on fd 1) write to stderr instead
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(obj):
+        os.write(json_fd, (json.dumps(obj) + "\n").encode())
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -96,8 +104,11 @@ def main():
     import zk_amd
 
     dist = None
-    if world > 1:
+    if world > 1 or args.force_sharded:
         import torch.distributed as dist_mod
+
+        if world == 1 and "MASTER_ADDR" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
 
         dist = dist_mod
         if args.shared_device:
@@ -112,10 +123,10 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    if world > 1:
+    if dist is not None:
         result = bench_sharded(args, zk_amd, np, dist, rank, local_rank, world)
     elif args.workload == "gkr":
-        print(json.dumps(bench_gkr(args, zk_amd.Context(local_rank), zk_amd, np)))
+        emit(bench_gkr(args, zk_amd.Context(local_rank), zk_amd, np))
         return
     else:
         ctx = zk_amd.Context(local_rank)
@@ -150,11 +161,11 @@ def main():
     for k in ("absorb_ms", "inclusive_ms", "kernels", "int32_alu", "proof_check"):
         if k in result:
             out[k] = result[k]
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1 and args.workload == "mle":
         out["cpu_baseline"] = cpu_baseline(args.cpu_log_n)
     else:
         out["cpu_baseline"] = None
-    print(json.dumps(out))
+    emit(out)
     if dist is not None:
         dist.destroy_process_group()
 
