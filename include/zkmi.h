@@ -54,6 +54,16 @@ const char *zk_strerror(int status);
 const char *zk_last_error(const zk_ctx *ctx); /* text of the last ZK_E_HIP / ZK_E_COMM on this context */
 const char *zk_version(void);
 
+/* ---- host field helpers: the few ark-ff operations a caller needs around the prover ------- */
+void zk_fq_from_u64(uint64_t v, uint64_t out_mont[4]);                      /* T::from(u64) */
+void zk_fq_to_le32(const uint64_t a_mont[4], uint8_t out[32]);              /* into_bigint().to_bytes_le() */
+void zk_fq_from_le32_mod_order(const uint8_t in[32], uint64_t out_mont[4]); /* from_le_bytes_mod_order, transcript.rs:35 */
+void zk_fq_add(const uint64_t a[4], const uint64_t b[4], uint64_t out[4]);
+void zk_fq_sub(const uint64_t a[4], const uint64_t b[4], uint64_t out[4]);
+void zk_fq_mul(const uint64_t a[4], const uint64_t b[4], uint64_t out[4]);
+/* UnivariatePolynomial::evaluate (dense_coefficient_form.rs:20-34), coefficients ascending */
+void zk_unipoly_evaluate(const uint64_t *coeffs, size_t n, const uint64_t x[4], uint64_t out[4]);
+
 /* ---- context ------------------------------------------------------------------------- */
 int zk_ctx_create(int device_id, zk_ctx **out);
 /* the same on a stream the caller owns (e.g. the current stream of the host framework that also

@@ -66,3 +66,41 @@ def test_sum2x2_2pow22_final_claim_matches_factor_evaluations():
     assert ok and np.array_equal(ch, pts)
     vals = [O.mont_to_ints(t.evaluate([c for c in pts]).get_evaluation_points())[0] for t in tabs]
     assert O.mont_to_ints(final)[0] == (vals[0] * vals[1] + vals[2] * vals[3]) % P
+
+
+def test_sumcheck_2pow28_headline_size():
+    """config 3's table size (2^28 entries, 8 GiB) on one GPU: prove, host partial_verify, device oracle check;
+    and the proof does not depend on the pass schedule (1 vs 4 rounds per pass)."""
+    ctx = zk_amd.Context(0)
+    poly = MLE.generate(SEED, 1 << 28, ctx=ctx)
+    tr = zk_amd.Transcript()
+    tr.append(b"fullsize-2^28")
+    claim, coeffs, ch = zk_amd.SumcheckProver.generate_round_polys(poly, tr)
+    assert coeffs.shape == (28, 2, 4)
+    tv = zk_amd.Transcript()
+    tv.append(b"fullsize-2^28")
+    ok, final, ch2 = zk_amd.SumcheckVerifier.partial_verify(zk_amd.SumCheckProof(claim, coeffs), tv)
+    assert ok and np.array_equal(ch, ch2)
+    val = poly.evaluate([c for c in ch]).get_evaluation_points()
+    assert list(val[0]) == list(final)
+    ctx.set_fold_batch(1, 1)              # one round per pass, fold tree: a different schedule and kernel
+    tr1 = zk_amd.Transcript()
+    tr1.append(b"fullsize-2^28")
+    claim1, coeffs1, ch1 = zk_amd.SumcheckProver.generate_round_polys(poly, tr1)
+    assert np.array_equal(claim1, claim) and np.array_equal(coeffs1, coeffs) and np.array_equal(ch1, ch)
+    del poly
+    ctx.close()
+
+
+def test_sum2x2_2pow26_config4_size():
+    """config 4: four factor tables of 2^26 entries; claim chain + final evaluation identity."""
+    n = 26
+    tabs = [MLE.generate(SEED + 70 + k, 1 << n) for k in range(4)]
+    f = zk_amd.SumPolynomial([zk_amd.ProductPolynomial(tabs[:2]), zk_amd.ProductPolynomial(tabs[2:])])
+    proof0, pts = zk_amd.SumcheckProver.generate_proof_for_partial_verify(O.fq1(0), f, zk_amd.Transcript())
+    g0 = O.mont_to_ints(proof0.round_polys[0])
+    claim = (2 * g0[0] + g0[1] + g0[2]) % P
+    ok, final, ch = zk_amd.SumcheckVerifier.partial_verify(zk_amd.SumCheckProof(O.fq1(claim), proof0.round_polys), zk_amd.Transcript())
+    assert ok and np.array_equal(ch, pts)
+    vals = [O.mont_to_ints(t.evaluate([c for c in pts]).get_evaluation_points())[0] for t in tabs]
+    assert O.mont_to_ints(final)[0] == (vals[0] * vals[1] + vals[2] * vals[3]) % P

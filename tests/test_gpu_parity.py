@@ -236,7 +236,7 @@ def test_partial_sumcheck_reference_vector(ctx):
     assert np.array_equal(proof.round_polys, ocoeffs) and np.array_equal(pts, och)
 
 
-@pytest.mark.parametrize("log_n", [1, 2, 4, 7, 10, 13])
+@pytest.mark.parametrize("log_n", [1, 2, 4, 6, 7, 10, 13])
 def test_sum2x2_vs_oracle_random_full_range(ctx, log_n):
     n = 1 << log_n
     tabs = [O.ints_to_mont(rand_table(n, 400 + 10 * log_n + k)) if log_n <= 10 else O.gen_table(SEED + 40 + k, 0, n)

@@ -26,6 +26,13 @@ SYMBOLS = [
     ("zk_strerror", C.c_char_p, [C.c_int]),
     ("zk_last_error", C.c_char_p, [_VP]),
     ("zk_version", C.c_char_p, []),
+    ("zk_fq_from_u64", None, [C.c_uint64, u64p]),
+    ("zk_fq_to_le32", None, [u64p, u8p]),
+    ("zk_fq_from_le32_mod_order", None, [u8p, u64p]),
+    ("zk_fq_add", None, [u64p, u64p, u64p]),
+    ("zk_fq_sub", None, [u64p, u64p, u64p]),
+    ("zk_fq_mul", None, [u64p, u64p, u64p]),
+    ("zk_unipoly_evaluate", None, [u64p, C.c_size_t, u64p, u64p]),
     ("zk_ctx_create", C.c_int, [C.c_int, C.POINTER(_VP)]),
     ("zk_ctx_create_on_stream", C.c_int, [C.c_int, _VP, C.POINTER(_VP)]),
     ("zk_ctx_destroy", None, [_VP]),

@@ -86,6 +86,20 @@ int zk_ctx_synchronize(zk_ctx* c) {
     return ZK_OK;
 }
 
+// ---- host field helpers (what ark-ff gives the Rust caller; used by the C++/Python host layers) ----
+void zk_fq_from_u64(uint64_t v, uint64_t out[4]) { zkh::store(out, zkh::from_u64(v)); }          // T::from(u64)
+void zk_fq_to_le32(const uint64_t a[4], uint8_t out[32]) { zkh::to_le32(zkh::load(a), out); }     // into_bigint().to_bytes_le()
+void zk_fq_from_le32_mod_order(const uint8_t in[32], uint64_t out[4]) { zkh::store(out, zkh::from_le32_mod_order(in)); }
+void zk_fq_add(const uint64_t a[4], const uint64_t b[4], uint64_t out[4]) { zkh::store(out, zkh::add(zkh::load(a), zkh::load(b))); }
+void zk_fq_sub(const uint64_t a[4], const uint64_t b[4], uint64_t out[4]) { zkh::store(out, zkh::sub(zkh::load(a), zkh::load(b))); }
+void zk_fq_mul(const uint64_t a[4], const uint64_t b[4], uint64_t out[4]) { zkh::store(out, zkh::mul(zkh::load(a), zkh::load(b))); }
+// UnivariatePolynomial::evaluate (dense_coefficient_form.rs:20-34): sum_i coeffs[i] x^i
+void zk_unipoly_evaluate(const uint64_t* coeffs, size_t n, const uint64_t x[4], uint64_t out[4]) {
+    std::vector<Fq> c(n);
+    for (size_t i = 0; i < n; ++i) c[i] = zkh::load(coeffs + 4 * i);
+    zkh::store(out, zkh::poly_eval(c.data(), n, zkh::load(x)));
+}
+
 // ---- transcript -----------------------------------------------------------------------------
 zk_transcript* zk_transcript_new(void) { return new (std::nothrow) zk_transcript(); }
 zk_transcript* zk_transcript_clone(const zk_transcript* t) { return t ? new (std::nothrow) zk_transcript(*t) : nullptr; }
