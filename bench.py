@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--cpu-log-n", type=int, default=24, help="bounded CPU sample size (2^k entries)")
     ap.add_argument("--fold-batch", type=int, default=0, help="rounds bound per device pass (0 = library default)")
     ap.add_argument("--fold-variant", type=int, default=0, help="0 eq-weight inner product, 1 tree, 2 tree+double buffer")
+    ap.add_argument("--deg2-rounds", type=int, default=0, help="degree-2 prover: rounds per device pass (1 or 2; 0 = library default, 2)")
     ap.add_argument("--weak", action="store_true", help="multi-GPU: 2^log_n entries PER GPU instead of in total")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for the multi-GPU exchange")
     ap.add_argument("--shared-device", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
@@ -201,7 +202,10 @@ def bench_single(args, ctx, zk_amd, np):
         def step():
             return zk_amd.SumcheckProver.generate_proof_for_partial_verify(claim, f, base.clone())
 
-        kernel, workload = "fold4_eval3", f"degree-2 sumcheck Sum[Prod[f,g],Prod[h,k]], 4 x 2^{args.log_n} entries, 1 GPU"
+        if args.deg2_rounds:
+            ctx.set_deg2_rounds_per_pass(args.deg2_rounds)
+        kernel = "fold4_eval3" if args.deg2_rounds == 1 else "fold2x4_sum9"
+        workload = f"degree-2 sumcheck Sum[Prod[f,g],Prod[h,k]], 4 x 2^{args.log_n} entries, 1 GPU"
 
     for _ in range(args.warmup):
         step()
@@ -220,7 +224,7 @@ def bench_single(args, ctx, zk_amd, np):
     ms_per_step = dt * 1e3 / args.steps
 
     kernels = {}
-    for name in ("block_sums", "multifold", "eval3", "fold4_eval3"):
+    for name in ("block_sums", "multifold", "eval3", "fold4_eval3", "sum9", "fold2x4_sum9"):
         p = ctx.prof_read(name)
         if p["launches"]:
             kernels[name] = {
@@ -234,7 +238,7 @@ def bench_single(args, ctx, zk_amd, np):
         "frac": dom["achieved_GBs"] / HBM_PEAK_GBS, "traffic": pmc_traffic(kernel, args.log_n),
         "note": "achieved = algorithmic bytes of all launches of the kernel in the timed steps / their summed "
                 "HIP-event durations (multifold: 32 B per input entry read + 32 B per output entry written; "
-                "fold4_eval3: 48 B per input entry per table)",
+                "fold4_eval3: 48 B per input entry per table; fold2x4_sum9: 32 B per input + 32 B per output entry per table)",
     }
     # int32-ALU side: Montgomery multiplies per second from the in-register probe
     blocks, iters = 2048, 2000

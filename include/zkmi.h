@@ -236,7 +236,11 @@ int zk_gkr_verify(zk_ctx *ctx, zk_circuit *circuit, zk_transcript *transcript, c
  * 2 = fold tree with register double-buffering; 3 = as 0 with 2-element load groups; 4 / 5 / 6 = as 0 with a
  * rolling window of 8 / 4 / 16 element loads in flight per lane.  Proof bytes do not depend on either. */
 int zk_ctx_set_fold_batch(zk_ctx *ctx, int rounds_per_pass, int variant);
-enum { ZK_K_BLOCK_SUMS = 0, ZK_K_MULTIFOLD = 1, ZK_K_FOLD = 2, ZK_K_EVAL3 = 3, ZK_K_FOLD4_EVAL3 = 4, ZK_K_COUNT = 8 };
+/* Rounds bound per device pass by the degree-2 prover: 2 (default; nine sums serve two rounds) or 1 (one
+ * evaluation triple per pass).  Proof bytes do not depend on it. */
+int zk_ctx_set_deg2_rounds_per_pass(zk_ctx *ctx, int rounds);
+enum { ZK_K_BLOCK_SUMS = 0, ZK_K_MULTIFOLD = 1, ZK_K_FOLD = 2, ZK_K_EVAL3 = 3, ZK_K_FOLD4_EVAL3 = 4, ZK_K_SUM9 = 5, ZK_K_FOLD2X4_SUM9 = 6,
+       ZK_K_COUNT = 8 };
 /* per-kernel HIP-event timing of the launches made by the provers on this context */
 int zk_prof_enable(zk_ctx *ctx, int on);
 int zk_prof_reset(zk_ctx *ctx);
@@ -244,7 +248,8 @@ int zk_prof_reset(zk_ctx *ctx);
 int zk_prof_collect(zk_ctx *ctx);
 /* totals since the last reset: launches, elapsed ms (HIP events on the context stream) and
  * ALGORITHMIC bytes (block sums 32 B/entry; m-round fold 32 B per input entry + 32 B per
- * output entry; degree-2 kernels 32 B (eval) / 48 B (fold+eval) per input entry per table) */
+ * output entry; degree-2 kernels 32 B (eval, sum9) / 48 B (fold+eval) per input entry per table, two-round
+ * fold 32 B per input entry + 32 B per output entry per table) */
 int zk_prof_read(zk_ctx *ctx, int kernel, uint64_t *launches, double *ms, uint64_t *alg_bytes);
 /* Montgomery-multiply throughput probe: `iters` dependent multiplies per lane on `blocks` x 256
  * lanes; returns elapsed ms.  Used for the int32-ALU roofline figure. */

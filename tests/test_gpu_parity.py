@@ -261,3 +261,24 @@ def test_sum2x2_shape_errors(ctx):
     with pytest.raises(zk_amd.ZkError) as ei:      # F9: degree() = 1 cannot be interpolated at [0,1,2]
         zk_amd.SumcheckProver.generate_proof_for_partial_verify(O.fq1(0), one_term, zk_amd.Transcript())
     assert ei.value.status == 5
+
+
+@pytest.mark.parametrize("rounds_per_pass", [1, 2])
+def test_sum2x2_both_schedules_give_the_oracle_proof(rounds_per_pass):
+    """Two rounds per device pass (nine sums) or one (three evaluations): an execution schedule, same proof bytes."""
+    c = zk_amd.Context(0)
+    c.set_deg2_rounds_per_pass(rounds_per_pass)
+    for log_n in (2, 3, 6, 7, 8, 9, 11, 12, 14):
+        n = 1 << log_n
+        tabs = [O.gen_table(SEED + 90 + k, 0, n) for k in range(4)]
+        m = [MLE(t, ctx=c) for t in tabs]
+        f = zk_amd.SumPolynomial([zk_amd.ProductPolynomial(m[:2]), zk_amd.ProductPolynomial(m[2:])])
+        tr, otr = zk_amd.Transcript(), O.OTranscript()
+        proof, pts = zk_amd.SumcheckProver.generate_proof_for_partial_verify(O.fq1(5), f, tr)
+        ocoeffs, och = O.sumcheck_prove_sum([[tabs[0], tabs[1]], [tabs[2], tabs[3]]], O.fq1(5), otr)
+        assert np.array_equal(proof.round_polys, ocoeffs), (rounds_per_pass, log_n)
+        assert np.array_equal(pts, och) and tr.peek_digest() == otr.peek_digest()
+        for t, src in zip(m, tabs):
+            assert np.array_equal(t.get_evaluation_points(), src)      # the factor tables are left unmodified
+    with pytest.raises(zk_amd.ZkError):
+        c.set_deg2_rounds_per_pass(3)

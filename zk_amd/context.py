@@ -5,7 +5,7 @@ import ctypes as C
 
 from ._lib import check, lib
 
-KERNELS = {"block_sums": 0, "multifold": 1, "fold": 2, "eval3": 3, "fold4_eval3": 4}
+KERNELS = {"block_sums": 0, "multifold": 1, "fold": 2, "eval3": 3, "fold4_eval3": 4, "sum9": 5, "fold2x4_sum9": 6}
 
 
 class Context:
@@ -35,6 +35,10 @@ class Context:
         """Tuning knob of the single-MLE prover (proof bytes do not depend on it).
         variant 0 = eq-weight inner product (default), 1 = fold tree, 2 = tree + double buffering."""
         check(lib().zk_ctx_set_fold_batch(self.h, rounds_per_pass, variant))
+
+    def set_deg2_rounds_per_pass(self, rounds: int):
+        """Degree-2 prover schedule: 2 rounds per device pass (default) or 1.  Proof bytes do not depend on it."""
+        check(lib().zk_ctx_set_deg2_rounds_per_pass(self.h, rounds))
 
     # ---- measurement hooks
     def prof_enable(self, on: bool = True):

@@ -32,6 +32,13 @@ int launch_sum_all(const void* T, size_t n, void* partials, hipStream_t st);
 int launch_eval3(const void* const t[4], size_t half, void* partials, hipStream_t st);
 int launch_fold4_eval3(const void* const s[4], void* const d[4], size_t q, const uint64_t r[4], void* partials, hipStream_t st);
 void launch_fold4(const void* const s[4], void* const d[4], size_t half, const uint64_t r[4], hipStream_t st);
+// degree-2 branch, two rounds per pass (kernels.hip): out[3Y + t] (9 elements) = the nine sums of four tables of 4q
+// entries; partials must hold 18 * kMaxBlocks9 elements
+static constexpr int kMaxBlocks9 = 1024;
+void launch_sum9(const void* const t[4], size_t q, void* partials, void* out, hipStream_t st);
+// bind the two top variables of four tables of 4*outlen entries (w28: the 4 eq weights as for launch_multifold_lazy)
+// into d[] (outlen entries each)
+void launch_fold2_tables(const void* const s[4], void* const d[4], size_t outlen, const uint32_t* w28, hipStream_t st);
 void launch_from_le32(const void* in, void* out, size_t n, hipStream_t st);
 void launch_to_le32(const void* in, void* out, size_t n, hipStream_t st);
 void launch_generate(void* out, uint64_t seed, uint64_t first, uint64_t step, size_t n, hipStream_t st);

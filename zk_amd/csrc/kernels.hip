@@ -384,6 +384,109 @@ __global__ void __launch_bounds__(kThreads) k_fold4(Tab4 S, Tab4w D, size_t half
     }
 }
 
+// ---- degree-2 branch, TWO rounds per pass ---------------------------------------------------------
+// Index = (b1, b2, j): b1, b2 the two top variables, j < q = len/4.  For one product term P = F*G and
+// Y in {0,1,2} let f0 = F(0,Y,j), f1 = F(1,Y,j) (F(b1,Y,j) = F[b1,0,j] + Y (F[b1,1,j] - F[b1,0,j])), df = f1 - f0.
+// After binding b1 := r the term is (f0 + r df)(g0 + r dg) = f0 g0 + r (f1 g1 - f0 g0 - df dg) + r^2 df dg, so
+// the nine sums  S[3Y + 0] = sum f0 g0,  S[3Y + 1] = sum f1 g1,  S[3Y + 2] = sum df dg  (over j and both terms)
+// give BOTH the current round's evaluations (prover.rs:93-100: ev(X) = sum_{Y in {0,1}} [S0 + X (S1-S0-S2) + X^2 S2])
+// and, once r is known, the next round's (ev'(Y) = S0 + r (S1-S0-S2) + r^2 S2): one sweep and one host round
+// trip per TWO rounds, and the fold that follows binds both variables at once.  Same field values as the
+// reference's per-round computation (exact arithmetic).
+// Work split: the fold and the sums are separate sweeps, each spread over as many lanes as the data allows --
+// one lane per (table, output) in the fold, one per (j, term[, Y]) in the sums -- because most calls (GKR layers)
+// run on tables of <= 2^20 entries where the serial chain per lane, not bandwidth, sets the time.
+
+// the three products of one term at one Y from its eight values x[factor][b1][b2]
+template <int Y>
+__device__ __forceinline__ void sum9_products(fq* __restrict__ acc3, const fq (&x)[2][2][2]) {
+    fq v0[2], v1[2], d[2];
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+        if (Y == 0) { v0[f] = x[f][0][0]; v1[f] = x[f][1][0]; }
+        else if (Y == 1) { v0[f] = x[f][0][1]; v1[f] = x[f][1][1]; }
+        else { v0[f] = fq_sub(fq_dbl(x[f][0][1]), x[f][0][0]); v1[f] = fq_sub(fq_dbl(x[f][1][1]), x[f][1][0]); }
+        d[f] = fq_sub(v1[f], v0[f]);
+    }
+    acc3[0] = fq_add(acc3[0], fq_mul(v0[0], v0[1]));
+    acc3[1] = fq_add(acc3[1], fq_mul(v1[0], v1[1]));
+    acc3[2] = fq_add(acc3[2], fq_mul(d[0], d[1]));
+}
+
+// YSPLIT = false: gridDim.y = 2 (term); a lane forms all nine products of its term (tables read once): large tables.
+//   partials[(term * gridDim.x + bx) * 9 + 3Y + t]
+// YSPLIT = true:  gridDim.y = 6 (term * 3 + Y); a lane forms the three products of one Y: small tables, 3x the lanes.
+//   partials[((term * 3 + Y) * gridDim.x + bx) * 3 + t]
+template <bool YSPLIT>
+__global__ void __launch_bounds__(kThreads) k_sum9(Tab4 T, size_t q, fq* __restrict__ partials) {
+    constexpr int NS = YSPLIT ? 3 : 9;
+    const int term = YSPLIT ? blockIdx.y / 3 : blockIdx.y;
+    const int Ysel = YSPLIT ? blockIdx.y % 3 : -1;
+    const fq* __restrict__ F = T.t[2 * term];
+    const fq* __restrict__ G = T.t[2 * term + 1];
+    fq acc[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) acc[s] = fq_zero();
+    const size_t stride = (size_t)gridDim.x * kThreads;
+    for (size_t j = (size_t)blockIdx.x * kThreads + threadIdx.x; j < q; j += stride) {
+        fq x[2][2][2];
+        if (!YSPLIT || Ysel != 1) { // b2 = 0 values: needed by Y = 0 and Y = 2
+            x[0][0][0] = fq_load_stream(F + j);
+            x[0][1][0] = fq_load_stream(F + 2 * q + j);
+            x[1][0][0] = fq_load_stream(G + j);
+            x[1][1][0] = fq_load_stream(G + 2 * q + j);
+        }
+        if (!YSPLIT || Ysel != 0) { // b2 = 1 values: needed by Y = 1 and Y = 2
+            x[0][0][1] = fq_load_stream(F + q + j);
+            x[0][1][1] = fq_load_stream(F + 3 * q + j);
+            x[1][0][1] = fq_load_stream(G + q + j);
+            x[1][1][1] = fq_load_stream(G + 3 * q + j);
+        }
+        if (YSPLIT) {
+            if (Ysel == 0) sum9_products<0>(acc, x);
+            else if (Ysel == 1) sum9_products<1>(acc, x);
+            else sum9_products<2>(acc, x);
+        } else {
+            sum9_products<0>(acc + 0, x);
+            sum9_products<1>(acc + (YSPLIT ? 0 : 3), x);
+            sum9_products<2>(acc + (YSPLIT ? 0 : 6), x);
+        }
+    }
+    block_sum_store<NS>(acc, partials + (size_t)blockIdx.y * gridDim.x * NS);
+}
+
+// second stage: block s = 3Y + t adds its sum's partials over both terms and all bx (fixed order)
+__global__ void __launch_bounds__(kThreads) k_reduce9(const fq* __restrict__ partials, int gx, int ysplit, fq* __restrict__ out) {
+    const int s = blockIdx.x, Y = s / 3, t = s % 3;
+    fq acc[1] = {fq_zero()};
+    for (int i = threadIdx.x; i < 2 * gx; i += kThreads) {
+        const int term = i / gx, bx = i % gx;
+        const size_t at = ysplit ? ((size_t)(term * 3 + Y) * gx + bx) * 3 + t : ((size_t)term * gx + bx) * 9 + s;
+        acc[0] = fq_add(acc[0], fq_load(partials + at));
+    }
+    block_sum_store<1>(acc, out);
+}
+
+// Bind the two top variables of all four tables at once: weights W = eq((r, s), b) * 2^280, b = 2 b1 + b2; one lane per
+// (table = blockIdx.y, output o): dst[o] = sum_b W[b] * src[b * outlen + o], one Montgomery reduction per output.
+__global__ void __launch_bounds__(kThreads) k_fold2_tables(Tab4 S, Tab4w D, size_t outlen, W28<2> W) {
+    const fq* __restrict__ src = S.t[blockIdx.y];
+    fq* __restrict__ dst = D.t[blockIdx.y];
+    const size_t stride = (size_t)gridDim.x * kThreads;
+    for (size_t o = (size_t)blockIdx.x * kThreads + threadIdx.x; o < outlen; o += stride) {
+        const fq in0 = fq_load_stream(src + o), in1 = fq_load_stream(src + outlen + o), in2 = fq_load_stream(src + 2 * outlen + o),
+                 in3 = fq_load_stream(src + 3 * outlen + o);
+        u64 a28[20];
+#pragma unroll
+        for (int k = 0; k < 20; ++k) a28[k] = 0;
+        fq28_mac(a28, in0, W.w[0]);
+        fq28_mac(a28, in1, W.w[1]);
+        fq28_mac(a28, in2, W.w[2]);
+        fq28_mac(a28, in3, W.w[3]);
+        fq_store(dst + o, fq28_redc(a28));
+    }
+}
+
 // ---- format conversion / generation ------------------------------------------------------
 // canonical little-endian 256-bit values (any value < 2^256) -> Montgomery table
 __global__ void __launch_bounds__(kThreads) k_from_le32(const fq* __restrict__ in, fq* __restrict__ out, size_t n) {
@@ -562,6 +665,29 @@ void launch_fold4(const void* const s[4], void* const d[4], size_t half, const u
     Tab4w D;
     for (int k = 0; k < 4; ++k) { S.t[k] = (const fq*)s[k]; D.t[k] = (fq*)d[k]; }
     hipLaunchKernelGGL(k_fold4, dim3(grid_for(half)), dim3(kThreads), 0, st, S, D, half, to_fq(r));
+}
+void launch_sum9(const void* const t[4], size_t q, void* partials, void* out, hipStream_t st) {
+    Tab4 T;
+    for (int k = 0; k < 4; ++k) T.t[k] = (const fq*)t[k];
+    size_t gx = (q + kThreads - 1) / kThreads;
+    if (gx < 1) gx = 1;
+    if (gx > (size_t)kMaxBlocks9) gx = kMaxBlocks9;
+    const bool ysplit = q < ((size_t)1 << 17); // small tables: three times the lanes, tables read twice (cache-resident)
+    if (ysplit) hipLaunchKernelGGL((k_sum9<true>), dim3((unsigned)gx, 6), dim3(kThreads), 0, st, T, q, (fq*)partials);
+    else hipLaunchKernelGGL((k_sum9<false>), dim3((unsigned)gx, 2), dim3(kThreads), 0, st, T, q, (fq*)partials);
+    hipLaunchKernelGGL(k_reduce9, dim3(9), dim3(kThreads), 0, st, (const fq*)partials, (int)gx, ysplit ? 1 : 0, (fq*)out);
+}
+void launch_fold2_tables(const void* const s[4], void* const d[4], size_t outlen, const uint32_t* w28, hipStream_t st) {
+    Tab4 S;
+    Tab4w D;
+    for (int k = 0; k < 4; ++k) { S.t[k] = (const fq*)s[k]; D.t[k] = (fq*)d[k]; }
+    W28<2> W;
+    for (int b = 0; b < 4; ++b)
+        for (int j = 0; j < 10; ++j) W.w[b][j] = w28[b * 10 + j];
+    size_t gx = (outlen + kThreads - 1) / kThreads;
+    if (gx < 1) gx = 1;
+    if (gx > (size_t)kMaxBlocks) gx = kMaxBlocks;
+    hipLaunchKernelGGL(k_fold2_tables, dim3((unsigned)gx, 4), dim3(kThreads), 0, st, S, D, outlen, W);
 }
 void launch_from_le32(const void* in, void* out, size_t n, hipStream_t st) {
     hipLaunchKernelGGL(k_from_le32, dim3(grid_for(n)), dim3(kThreads), 0, st, (const fq*)in, (fq*)out, n);

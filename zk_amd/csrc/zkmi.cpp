@@ -49,7 +49,7 @@ static int ctx_create(int device_id, bool own_stream, hipStream_t stream, zk_ctx
     };
     if (fail(hipSetDevice(device_id), "hipSetDevice") ||
         (own_stream && fail(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking), "hipStreamCreate")) ||
-        fail(hipMalloc(&c->partials, (size_t)zkk::kMaxBlocks * 3 * kElem), "hipMalloc partials") ||
+        fail(hipMalloc(&c->partials, (size_t)std::max(zkk::kMaxBlocks * 3, zkk::kMaxBlocks9 * 18) * kElem), "hipMalloc partials") ||
         fail(hipMalloc(&c->sums_dev, kSums * kElem), "hipMalloc sums") ||
         fail(hipHostMalloc((void**)&c->sums_host, kHostStage * kElem, hipHostMallocMapped), "hipHostMalloc sums") ||
         fail(hipHostGetDevicePointer(&c->sums_host_dev, c->sums_host, 0), "hipHostGetDevicePointer")) {
@@ -580,7 +580,8 @@ void host_sum2x2_rounds(zk_transcript* tr, std::vector<Fq>& T, size_t len, uint6
 // the round loop of the SumPolynomial branch on four device tables of `len` entries each;
 // final_out (optional, 4 elements): every table folded at ALL n challenges (the reference's
 // sum_poly after the last partial_evaluate, prover.rs:139) -- GKR needs W(r_b), W(r_c) from it
-int zki::prove_sum2x2_dev(zk_ctx* c, const void* const tables[4], size_t len, zk_transcript* tr, uint64_t* coeffs_out,
+// one round per device pass (k_eval3 / k_fold4_eval3)
+static int prove_sum2x2_single(zk_ctx* c, const void* const tables[4], size_t len, zk_transcript* tr, uint64_t* coeffs_out,
                           uint64_t* challenges_out, uint64_t* final_out) {
     const unsigned n = ilog2(len);
     if (n == 0) { // zero variables: no rounds, nothing appended
@@ -656,6 +657,87 @@ int zki::prove_sum2x2_dev(zk_ctx* c, const void* const tables[4], size_t len, zk
     }
     prof_collect(c);
     return ZK_OK;
+}
+
+// two rounds per device pass (kernels.hip, "degree-2 branch, TWO rounds per pass")
+static int prove_sum2x2_pairs(zk_ctx* c, const void* const tables[4], size_t len, zk_transcript* tr, uint64_t* coeffs_out,
+                              uint64_t* challenges_out, uint64_t* final_out) {
+    int rc = set_device(c);
+    if (rc) return rc;
+    const void* cur[4];
+    for (int k = 0; k < 4; ++k) cur[k] = tables[k];
+    size_t curlen = len;
+    unsigned k = 0; // round index
+    int pass = 0;
+    if (curlen > kHostTail) {
+        ProfScope ps(c, ZK_K_SUM9, (uint64_t)len * 32 * 4);
+        zkk::launch_sum9(cur, curlen / 4, c->partials, c->sums_host_dev, c->stream); // nine sums straight into pinned host memory
+    }
+    while (curlen > kHostTail) {
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        Fq S[9];
+        for (int i = 0; i < 9; ++i) S[i] = zkh::load(c->sums_host + 4 * i);
+        // round k binds b1: ev(X) = sum_{Y in {0,1}} [S0 + X (S1 - S0 - S2) + X^2 S2](Y)
+        Fq mid[3]; // S1 - S0 - S2 per Y
+        for (int Y = 0; Y < 3; ++Y) mid[Y] = zkh::sub(zkh::sub(S[3 * Y + 1], S[3 * Y]), S[3 * Y + 2]);
+        Fq ev[3];
+        ev[0] = zkh::add(S[0], S[3]);
+        ev[1] = zkh::add(S[1], S[4]);
+        {
+            Fq e2 = zkh::zero();
+            for (int Y = 0; Y < 2; ++Y) {
+                const Fq two_mid = zkh::add(mid[Y], mid[Y]), two_s2 = zkh::add(S[3 * Y + 2], S[3 * Y + 2]);
+                e2 = zkh::add(e2, zkh::add(zkh::add(S[3 * Y], two_mid), zkh::add(two_s2, two_s2)));
+            }
+            ev[2] = e2;
+        }
+        uint64_t rs[8];
+        const Fq r = host_round_deg2(tr, ev, coeffs_out + 12 * k);
+        zkh::store(rs, r);
+        // round k+1 binds b2 with b1 = r: ev'(Y) = S0 + r (S1 - S0 - S2) + r^2 S2
+        const Fq r2 = zkh::mul(r, r);
+        for (int Y = 0; Y < 3; ++Y) ev[Y] = zkh::add(zkh::add(S[3 * Y], zkh::mul(r, mid[Y])), zkh::mul(r2, S[3 * Y + 2]));
+        const Fq s2 = host_round_deg2(tr, ev, coeffs_out + 12 * (k + 1));
+        zkh::store(rs + 4, s2);
+        if (challenges_out) std::memcpy(challenges_out + 4 * k, rs, 2 * kElem);
+        k += 2;
+        // bind both variables in one sweep, then the nine sums of the result unless the host takes over
+        const size_t outlen = curlen / 4;
+        if ((rc = ensure_work(c, pass & 1, 4 * outlen * kElem))) return rc;
+        void* dst[4];
+        for (int t = 0; t < 4; ++t) dst[t] = (uint8_t*)c->work[pass & 1] + (size_t)t * outlen * kElem;
+        uint32_t w28[4 * 10];
+        eq_weights28(rs, 2, w28);
+        {
+            ProfScope ps(c, ZK_K_FOLD2X4_SUM9, (uint64_t)curlen * 32 * 4 + (uint64_t)outlen * 32 * 4);
+            zkk::launch_fold2_tables(cur, dst, outlen, w28, c->stream);
+        }
+        if (outlen > kHostTail) {
+            ProfScope ps(c, ZK_K_SUM9, (uint64_t)outlen * 32 * 4);
+            zkk::launch_sum9(dst, outlen / 4, c->partials, c->sums_host_dev, c->stream);
+        }
+        for (int t = 0; t < 4; ++t) cur[t] = dst[t];
+        curlen = outlen;
+        ++pass;
+    }
+    HIPCHK(c, hipGetLastError());
+    // the rest (<= kHostTail entries per table, at least 2 variables' worth unless len was tiny) on the host
+    for (int t = 0; t < 4; ++t)
+        HIPCHK(c, hipMemcpyAsync(c->sums_host + 4 * (size_t)t * curlen, cur[t], curlen * kElem, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    std::vector<Fq> T(4 * curlen);
+    for (size_t i = 0; i < 4 * curlen; ++i) T[i] = zkh::load(c->sums_host + 4 * i);
+    host_sum2x2_rounds(tr, T, curlen, coeffs_out + 12 * k, challenges_out ? challenges_out + 4 * k : nullptr, final_out);
+    prof_collect(c);
+    return ZK_OK;
+}
+
+int zki::prove_sum2x2_dev(zk_ctx* c, const void* const tables[4], size_t len, zk_transcript* tr, uint64_t* coeffs_out,
+                          uint64_t* challenges_out, uint64_t* final_out) {
+    if (len >= 2 && !coeffs_out) return ZK_E_ARG;
+    if (c->deg2_pairs && len >= 4) return prove_sum2x2_pairs(c, tables, len, tr, coeffs_out, challenges_out, final_out);
+    return prove_sum2x2_single(c, tables, len, tr, coeffs_out, challenges_out, final_out);
 }
 
 extern "C" {
@@ -823,6 +905,11 @@ int zk_ctx_set_fold_batch(zk_ctx* c, int rounds_per_pass, int variant) {
     c->lazy = variant == 0 || variant >= 3;
     c->lazy_group = variant == 3 ? 2 : variant == 4 ? 108 : variant == 5 ? 104 : variant == 6 ? 116 : 4;
     c->double_buffer = variant == 2;
+    return ZK_OK;
+}
+int zk_ctx_set_deg2_rounds_per_pass(zk_ctx* c, int rounds) {
+    if (!c || (rounds != 1 && rounds != 2)) return ZK_E_ARG;
+    c->deg2_pairs = rounds == 2;
     return ZK_OK;
 }
 int zk_prof_enable(zk_ctx* c, int on) {

@@ -64,6 +64,7 @@ struct zk_ctx {
     int fold_batch = 4;          // rounds bound per device pass (1..kMaxFoldBatch)
     bool double_buffer = false;  // register double-buffering in k_multifold (tree variant)
     bool lazy = true;            // inner-product form with one reduction per output (k_multifold_lazy)
+    bool deg2_pairs = true;      // degree-2 prover: two rounds per device pass (k_sum9 / k_fold2x4_sum9)
     int lazy_group = 4;          // elements per register load buffer in k_multifold_lazy (2 or 4)
     void* work[2] = {nullptr, nullptr};
     size_t work_cap[2] = {0, 0}; // bytes
