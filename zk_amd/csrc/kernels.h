@@ -39,6 +39,8 @@ void launch_sum9(const void* const t[4], size_t q, void* partials, void* out, hi
 // bind the two top variables of four tables of 4*outlen entries (w28: the 4 eq weights as for launch_multifold_lazy)
 // into d[] (outlen entries each)
 void launch_fold2_tables(const void* const s[4], void* const d[4], size_t outlen, const uint32_t* w28, hipStream_t st);
+// out[k*n + i] = t[k][i], k < 4, i < n
+void launch_gather4(const void* const t[4], size_t n, void* out, hipStream_t st);
 void launch_from_le32(const void* in, void* out, size_t n, hipStream_t st);
 void launch_to_le32(const void* in, void* out, size_t n, hipStream_t st);
 void launch_generate(void* out, uint64_t seed, uint64_t first, uint64_t step, size_t n, hipStream_t st);

@@ -487,6 +487,13 @@ __global__ void __launch_bounds__(kThreads) k_fold2_tables(Tab4 S, Tab4w D, size
     }
 }
 
+// the host tail of the degree-2 prover: four small tables (n entries each) into one contiguous buffer (table-major),
+// normally the device-mapped pinned staging buffer -- one launch instead of four copy commands
+__global__ void __launch_bounds__(kThreads) k_gather4(Tab4 T, size_t n, fq* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x;
+    if (i < 4 * n) fq_store(out + i, fq_load(T.t[i / n] + i % n));
+}
+
 // ---- format conversion / generation ------------------------------------------------------
 // canonical little-endian 256-bit values (any value < 2^256) -> Montgomery table
 __global__ void __launch_bounds__(kThreads) k_from_le32(const fq* __restrict__ in, fq* __restrict__ out, size_t n) {
@@ -672,10 +679,15 @@ void launch_sum9(const void* const t[4], size_t q, void* partials, void* out, hi
     size_t gx = (q + kThreads - 1) / kThreads;
     if (gx < 1) gx = 1;
     if (gx > (size_t)kMaxBlocks9) gx = kMaxBlocks9;
-    const bool ysplit = q < ((size_t)1 << 17); // small tables: three times the lanes, tables read twice (cache-resident)
+    const bool ysplit = q < ((size_t)1 << 21); // small tables: three times the lanes, tables read twice (mostly cache-resident)
     if (ysplit) hipLaunchKernelGGL((k_sum9<true>), dim3((unsigned)gx, 6), dim3(kThreads), 0, st, T, q, (fq*)partials);
     else hipLaunchKernelGGL((k_sum9<false>), dim3((unsigned)gx, 2), dim3(kThreads), 0, st, T, q, (fq*)partials);
     hipLaunchKernelGGL(k_reduce9, dim3(9), dim3(kThreads), 0, st, (const fq*)partials, (int)gx, ysplit ? 1 : 0, (fq*)out);
+}
+void launch_gather4(const void* const t[4], size_t n, void* out, hipStream_t st) {
+    Tab4 T;
+    for (int k = 0; k < 4; ++k) T.t[k] = (const fq*)t[k];
+    hipLaunchKernelGGL(k_gather4, dim3((unsigned)((4 * n + kThreads - 1) / kThreads)), dim3(kThreads), 0, st, T, n, (fq*)out);
 }
 void launch_fold2_tables(const void* const s[4], void* const d[4], size_t outlen, const uint32_t* w28, hipStream_t st) {
     Tab4 S;

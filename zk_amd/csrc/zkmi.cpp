@@ -611,8 +611,8 @@ static int prove_sum2x2_single(zk_ctx* c, const void* const tables[4], size_t le
         if (curlen <= kHostTail && curlen >= 2) {
             // small tables: one D2H of the four tables, the remaining rounds (and the last fold) on the host --
             // a round on the device costs a launch, a second stage and a sync whatever the size
-            for (int t = 0; t < 4; ++t)
-                HIPCHK(c, hipMemcpyAsync(c->sums_host + 4 * (size_t)t * curlen, cur[t], curlen * kElem, hipMemcpyDeviceToHost, c->stream));
+            zkk::launch_gather4(cur, curlen, c->sums_host_dev, c->stream);
+            HIPCHK(c, hipGetLastError());
             HIPCHK(c, hipStreamSynchronize(c->stream));
             std::vector<Fq> T(4 * curlen);
             for (size_t i = 0; i < 4 * curlen; ++i) T[i] = zkh::load(c->sums_host + 4 * i);
@@ -723,8 +723,8 @@ static int prove_sum2x2_pairs(zk_ctx* c, const void* const tables[4], size_t len
     }
     HIPCHK(c, hipGetLastError());
     // the rest (<= kHostTail entries per table, at least 2 variables' worth unless len was tiny) on the host
-    for (int t = 0; t < 4; ++t)
-        HIPCHK(c, hipMemcpyAsync(c->sums_host + 4 * (size_t)t * curlen, cur[t], curlen * kElem, hipMemcpyDeviceToHost, c->stream));
+    zkk::launch_gather4(cur, curlen, c->sums_host_dev, c->stream);
+    HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));
     std::vector<Fq> T(4 * curlen);
     for (size_t i = 0; i < 4 * curlen; ++i) T[i] = zkh::load(c->sums_host + 4 * i);
