@@ -23,3 +23,4 @@ python3 tools/prof_summary.py stats $OUT/${TAG}_trace > $OUT/${TAG}_kernel_stats
 timeout -s KILL 240 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_pmc_rd -- python3 $BENCH > $OUT/${TAG}_pmc_rd.log 2>&1 || { tail -30 $OUT/${TAG}_pmc_rd.log; exit 1; }
 timeout -s KILL 240 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_pmc_wr -- python3 $BENCH > $OUT/${TAG}_pmc_wr.log 2>&1 || { tail -30 $OUT/${TAG}_pmc_wr.log; exit 1; }
 { python3 tools/prof_summary.py pmc $OUT/${TAG}_pmc_rd; python3 tools/prof_summary.py pmc $OUT/${TAG}_pmc_wr; } > $OUT/${TAG}_hbm_traffic.txt && cat $OUT/${TAG}_hbm_traffic.txt
+python3 tools/prof_summary.py traffic $OUT/${TAG}_pmc_rd $OUT/${TAG}_pmc_wr 28 > $OUT/${TAG}_hbm_traffic.json

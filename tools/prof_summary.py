@@ -3,6 +3,7 @@
 
   prof_summary.py stats <dir>          per-kernel launches / total / avg / min / max (from *_kernel_trace.csv)
   prof_summary.py pmc   <dir>          per-kernel counter sums and the largest launch's values (from *_counter_collection.csv)
+  prof_summary.py traffic <fetch_dir> <write_dir> <log_n>   HBM bytes per launch of the bench kernels as JSON
 
 HBM bytes from the PMC counters follow /opt/skills/guides/MI355X_MICROARCH.md (HBM section):
 FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports exactly half of the bytes of a
@@ -58,7 +59,37 @@ def pmc(d):
             print(line)
 
 
+def traffic_json(rd_dir, wr_dir, log_n):
+    """HBM bytes per launch of the bench kernels from a FETCH_SIZE pass and a WRITE_SIZE pass -> JSON on stdout
+    (the file bench.py reads for roofline.traffic)."""
+    import json
+
+    names = {"k_multifold_lazy": "multifold", "k_multifold": "multifold", "k_multifold_roll": "multifold", "k_block_sums": "block_sums",
+             "k_sum9": "sum9", "k_fold2_tables": "fold2x4_sum9", "k_eval3": "eval3", "k_fold4_eval3": "fold4_eval3"}
+    acc = defaultdict(lambda: {"launches": 0, "read_bytes": 0.0, "write_bytes": 0.0})
+    for d, counter, key, scale in ((rd_dir, "FETCH_SIZE", "read_bytes", 2 * 1024.0), (wr_dir, "WRITE_SIZE", "write_bytes", 1024.0)):
+        for f in find(d, "_counter_collection.csv"):
+            with open(f, newline="") as fh:
+                for r in csv.DictReader(fh):
+                    base = re.sub(r"<.*", "", short(r["Kernel_Name"]))
+                    if r["Counter_Name"] != counter or base not in names:
+                        continue
+                    a = acc[names[base]]
+                    a[key] += float(r["Counter_Value"]) * scale
+                    if counter == "FETCH_SIZE":
+                        a["launches"] += 1
+    for a in acc.values():
+        a["bytes_per_launch"] = (a["read_bytes"] + a["write_bytes"]) / max(a["launches"], 1)
+    print(json.dumps({
+        "source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) of the bench command; tools/prof_summary.py traffic",
+        "correction": "HBM read bytes = 2 * FETCH_SIZE KiB * 1024 (gfx950, 16 B/lane streams); write bytes = WRITE_SIZE KiB * 1024",
+        "log_n": int(log_n), "kernels": dict(acc)}, indent=1))
+
+
 if __name__ == "__main__":
-    if len(sys.argv) != 3 or sys.argv[1] not in ("stats", "pmc"):
+    if len(sys.argv) == 5 and sys.argv[1] == "traffic":
+        traffic_json(sys.argv[2], sys.argv[3], sys.argv[4])
+    elif len(sys.argv) == 3 and sys.argv[1] in ("stats", "pmc"):
+        (stats if sys.argv[1] == "stats" else pmc)(sys.argv[2])
+    else:
         raise SystemExit(__doc__)
-    (stats if sys.argv[1] == "stats" else pmc)(sys.argv[2])
