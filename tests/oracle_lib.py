@@ -283,3 +283,17 @@ def gkr_prove(circuit: OCircuit, transcript: OTranscript, inputs: np.ndarray) ->
 def gkr_verify(inputs, circuit: OCircuit, transcript: OTranscript, proof: OGkrProof) -> bool:
     inputs = np.ascontiguousarray(inputs, dtype=np.uint64).reshape(-1, 4)
     return bool(lib().orc_gkr_verify(ptr(inputs), C.c_size_t(inputs.shape[0]), circuit.h, transcript.h, proof.h))
+
+
+def sumcheck_prove_fast(table: np.ndarray, absorb: bool = True, threads: int = 0):
+    """The optimised OpenMP CPU variant (oracle/fast.c).  -> (claim, coeffs (n,2,4), challenges (n,4))"""
+    table = np.ascontiguousarray(table, dtype=np.uint64).reshape(-1, 4)
+    n = table.shape[0]
+    nv = max(n.bit_length() - 1, 0)
+    claim = np.empty(4, dtype=np.uint64)
+    coeffs = np.empty((max(nv, 1), 2, 4), dtype=np.uint64)
+    ch = np.empty((max(nv, 1), 4), dtype=np.uint64)
+    rc = lib().orc_sumcheck_prove_fast(ptr(table), C.c_size_t(n), C.c_int(int(absorb)), C.c_int(threads), ptr(claim), ptr(coeffs), ptr(ch))
+    if rc:
+        raise ValueError(f"oracle error {rc}")
+    return claim, coeffs[:nv], ch[:nv]
