@@ -46,6 +46,15 @@ __global__ void __launch_bounds__(256) k_mem2(const fq* __restrict__ src, fq* __
             u32x4* g = reinterpret_cast<u32x4*>(dst + (i - lane)); // the wave's 64 outputs are contiguous; Lout is a multiple of 64 here
             g[lane] = c0;
             g[64 + lane] = c1;
+        } else if (STORE >= 4) {
+            // explicit cache-policy bits on the store (gfx940+: sc0, sc1, nt)
+            u32x4 lo = {o.v[0], o.v[1], o.v[2], o.v[3]}, hi = {o.v[4], o.v[5], o.v[6], o.v[7]};
+            const fq* p = dst + i;
+            if (STORE == 4) asm volatile("global_store_dwordx4 %0, %1, off sc0\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc0" ::"v"(p), "v"(lo), "v"(hi) : "memory");
+            if (STORE == 5) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc1" ::"v"(p), "v"(lo), "v"(hi) : "memory");
+            if (STORE == 6) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc0 sc1" ::"v"(p), "v"(lo), "v"(hi) : "memory");
+            if (STORE == 7) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc0 sc1 nt" ::"v"(p), "v"(lo), "v"(hi) : "memory");
+            if (STORE == 8) asm volatile("global_store_dwordx4 %0, %1, off nt\n\tglobal_store_dwordx4 %0, %2, off offset:16 nt" ::"v"(p), "v"(lo), "v"(hi) : "memory");
         } else if (STORE == 2) {
             u32x4* q = reinterpret_cast<u32x4*>(dst + i);
             u32x4 lo = {o.v[0], o.v[1], o.v[2], o.v[3]}, hi = {o.v[4], o.v[5], o.v[6], o.v[7]};
@@ -152,6 +161,11 @@ int main(int argc, char** argv) {
     RUN2(16, 8, 1, Lout, Lout, "16 streams, plain store");
     RUN2(16, 8, 2, Lout, Lout, "16 streams, nontemporal store");
     RUN2(16, 8, 3, Lout, Lout, "16 streams, LDS-transposed contiguous store");
+    RUN2(16, 8, 4, Lout, Lout, "16 streams, store sc0");
+    RUN2(16, 8, 5, Lout, Lout, "16 streams, store sc1");
+    RUN2(16, 8, 6, Lout, Lout, "16 streams, store sc0 sc1");
+    RUN2(16, 8, 7, Lout, Lout, "16 streams, store sc0 sc1 nt");
+    RUN2(16, 8, 8, Lout, Lout, "16 streams, store nt");
     RUN2(8, 8, 0, 2 * Lout, 2 * Lout, "8 streams, no store");
     RUN2(8, 8, 1, 2 * Lout, 2 * Lout, "8 streams, plain store");
     RUN2(4, 4, 0, 4 * Lout, 4 * Lout, "4 streams, no store");
