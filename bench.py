@@ -39,6 +39,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-log-n", type=int, default=24, help="bounded CPU sample size (2^k entries)")
     ap.add_argument("--fold-batch", type=int, default=0, help="rounds bound per device pass (0 = library default)")
+    ap.add_argument("--wide-batch", type=int, default=-1, help="rounds bound by a pass over a large table (5..8, 0 = off, -1 = library default 8)")
+    ap.add_argument("--wide-min-log-out", type=int, default=16, help="wide passes are taken while the folded table keeps >= 2^k entries")
     ap.add_argument("--fold-variant", type=int, default=0, help="0 eq-weight inner product, 1 tree, 2 tree+double buffer")
     ap.add_argument("--deg2-rounds", type=int, default=0, help="degree-2 prover: rounds per device pass (1 or 2; 0 = library default, 2)")
     ap.add_argument("--weak", action="store_true", help="multi-GPU: 2^log_n entries PER GPU instead of in total")
@@ -142,6 +144,8 @@ def main():
         ctx = zk_amd.Context(local_rank)
         if args.fold_batch:
             ctx.set_fold_batch(args.fold_batch, args.fold_variant)
+        if args.wide_batch >= 0:
+            ctx.set_wide_fold(args.wide_batch, args.wide_min_log_out)
         result = bench_single(args, ctx, zk_amd, np)
 
     torch.cuda.synchronize()
@@ -282,7 +286,9 @@ def bench_sharded(args, zk_amd, np, dist, rank, local_rank, world):
     ctx = sharded.torch_stream_context(local_rank)
     if args.fold_batch:
         ctx.set_fold_batch(args.fold_batch, args.fold_variant)
-    fold_batch = args.fold_batch or sharded.MAX_FOLD_BATCH
+    if args.wide_batch >= 0:
+        ctx.set_wide_fold(args.wide_batch, args.wide_min_log_out)
+    fold_batch = None  # the library's schedule (zk_shard_next_batch): the same passes as the single-GPU prover
     base = zk_amd.Transcript()
     base.append(b"bench: table absorb skipped (sharded run; SURVEY.md H1)")
     if args.workload == "mle":
@@ -297,7 +303,7 @@ def bench_sharded(args, zk_amd, np, dist, rank, local_rank, world):
 
         dom_kernel, names = "multifold", ("block_sums", "multifold")
         what = f"single-MLE sumcheck, 2^{log_total} entries"
-        exchange = f"all-gather of 2^m block sums per pass ({dist.get_backend()}), {fold_batch} rounds per pass"
+        exchange = f"all-gather of 2^m block sums per pass ({dist.get_backend()}), library pass schedule"
     else:
         tabs = [zk_amd.MultiLinearPolynomial.generate(SEED + k, n_local, first=rank, step=world, ctx=ctx) for k in range(4)]
 

@@ -149,6 +149,12 @@ int zk_sumcheck_rounds_from_block_sums(zk_transcript *t, const uint64_t *sums, i
 int zk_shard_begin(zk_ctx *ctx, const zk_mle *local_table, zk_shard **out); /* the table is not modified */
 void zk_shard_end(zk_shard *s);
 int zk_shard_vars_left(const zk_shard *s);
+/* how many rounds (m, 1..8) a pass should bind once `after_binding` more variables of the current local table
+ * are bound (0: the next pass; the m of the pass being issued: the m_next to give zk_shard_fold): the context's
+ * wide batch while the table is large, its default batch after that (zk_ctx_set_fold_batch /
+ * zk_ctx_set_wide_fold).  Any m <= vars_left is valid for zk_shard_block_sums / zk_shard_fold; this is the
+ * schedule zk_sumcheck_prove_mle uses.  0 when no variable is left, -1 on a bad argument. */
+int zk_shard_next_batch(const zk_shard *s, int after_binding);
 /* sums_dev_out (device, 2^m elements) = sums of the 2^m contiguous blocks of the current local table */
 int zk_shard_block_sums(zk_shard *s, int m, void *sums_dev_out);
 /* bind the top m variables at r[0..m) (m x partially_evaluate((0, r)), evaluation_form.rs:163-192) and
@@ -231,11 +237,16 @@ int zk_gkr_verify(zk_ctx *ctx, zk_circuit *circuit, zk_transcript *transcript, c
                   const uint64_t *coeffs, int *ok_out);
 
 /* ---- tuning / measurement hooks (no reference counterpart) ---------------------------- */
-/* Rounds bound per device pass by the single-MLE prover (1..4, default 4) and the fold kernel
- * variant: 0 = inner product with eq weights, one reduction per output (default); 1 = fold tree;
+/* Rounds bound per device pass by the single-MLE prover (1..8, default 4) and the fold kernel
+ * variant (passes of 5..8 rounds always use the wide kernel): 0 = inner product with eq weights, one reduction per output (default); 1 = fold tree;
  * 2 = fold tree with register double-buffering; 3 = as 0 with 2-element load groups; 4 / 5 / 6 = as 0 with a
  * rolling window of 8 / 4 / 16 element loads in flight per lane.  Proof bytes do not depend on either. */
 int zk_ctx_set_fold_batch(zk_ctx *ctx, int rounds_per_pass, int variant);
+/* Passes over a LARGE table bind up to `rounds` variables at once (5..8, default 8; 0 = off): as many as leave
+ * the folded table at least 2^min_log_out entries (default 16), when that is `rounds` itself or at least two more
+ * than the default batch.  At 2^8 read streams per store stream the pass runs at the read-only HBM rate
+ * (fold-pass ceiling).  Proof bytes do not depend on it. */
+int zk_ctx_set_wide_fold(zk_ctx *ctx, int rounds, int min_log_out);
 /* Rounds bound per device pass by the degree-2 prover: 2 (default; nine sums serve two rounds) or 1 (one
  * evaluation triple per pass).  Proof bytes do not depend on it. */
 int zk_ctx_set_deg2_rounds_per_pass(zk_ctx *ctx, int rounds);

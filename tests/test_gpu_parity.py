@@ -157,7 +157,7 @@ def test_sumcheck_vs_oracle_random_full_range(ctx, log_n):
 
 
 @pytest.mark.parametrize("batch,db", [(1, 0), (1, 1), (1, 2), (2, 0), (2, 1), (2, 2), (2, 3), (3, 0), (3, 1), (3, 2), (3, 3), (4, 0), (4, 1), (4, 3),
-                                      (3, 4), (3, 5), (4, 4), (4, 5), (4, 6)])
+                                      (3, 4), (3, 5), (4, 4), (4, 5), (4, 6), (5, 0), (6, 0), (7, 0), (8, 0), (8, 1)])
 def test_sumcheck_every_fold_batch_setting_gives_the_same_proof(batch, db):
     """Rounds-per-pass batching is an execution schedule, not a protocol change: proofs are identical."""
     c = zk_amd.Context(0)
@@ -171,7 +171,31 @@ def test_sumcheck_every_fold_batch_setting_gives_the_same_proof(batch, db):
         assert np.array_equal(proof.round_polys, ocoeffs), (batch, db, log_n)
         assert np.array_equal(ch, och), (batch, db, log_n)
     with pytest.raises(zk_amd.ZkError):
-        c.set_fold_batch(5, 0)
+        c.set_fold_batch(9, 0)
+
+
+@pytest.mark.parametrize("wide,min_log_out", [(8, 2), (8, 5), (7, 3), (6, 0), (5, 4), (0, 17)])
+def test_sumcheck_wide_first_passes_give_the_same_proof(wide, min_log_out):
+    """The pass schedule (wide 2^m-stream passes while the table is large, the default batch after that) is not
+    part of the protocol: the thresholds are lowered here so that small tables take one or more wide passes."""
+    c = zk_amd.Context(0)
+    c.set_wide_fold(wide, min_log_out)
+    for log_n in (4, 9, 10, 11, 13, 16, 18):
+        table = O.gen_table(SEED + 80 + log_n, 0, 1 << log_n)
+        poly = MLE(table, ctx=c)
+        proof, ch = zk_amd.SumcheckProver.generate_sumcheck_proof(poly, return_challenges=True)
+        oclaim, ocoeffs, och = O.sumcheck_prove(table)
+        assert list(proof.initial_claim_sum) == list(oclaim), (wide, min_log_out, log_n)
+        assert np.array_equal(proof.round_polys, ocoeffs), (wide, min_log_out, log_n)
+        assert np.array_equal(ch, och), (wide, min_log_out, log_n)
+        # evaluate() at a full point, and at a prefix of it, walks the same passes (verifier.rs:15-26)
+        pts = [r for r in ch]
+        assert np.array_equal(poly.evaluate(pts).get_evaluation_points(), O.mle_evaluate(table, pts)), (wide, min_log_out, log_n)
+        part = pts[: log_n - 2] + [None, None]
+        assert np.array_equal(poly.evaluate(part).get_evaluation_points(), O.mle_evaluate(table, part)), (wide, min_log_out, log_n)
+    for bad in ((4, 17), (9, 17), (8, -1)):
+        with pytest.raises(zk_amd.ZkError):
+            c.set_wide_fold(*bad)
 
 
 def test_sumcheck_reference_fail_vector_and_tampering(ctx):

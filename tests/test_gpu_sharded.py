@@ -36,6 +36,8 @@ def _worker(rank, world, port, backend, log_n, fold_batch, generated, outdir):
         dist.init_process_group(backend, rank=rank, world_size=world)
     try:
         ctx = sharded.torch_stream_context(0)
+        if fold_batch is None:  # the library's own schedule, with the wide passes switched on for tables this small
+            ctx.set_wide_fold(8, 2)
         n = 1 << log_n
         if generated:  # made on the device, strided
             local = zk_amd.MultiLinearPolynomial.generate(SEED, n // world, first=rank, step=world, ctx=ctx)
@@ -61,7 +63,8 @@ def _check(tmp_path, world, log_n):
         assert np.array_equal(d["ch"], och), f"rank {r}: challenges"
 
 
-@pytest.mark.parametrize("world,log_n,fold_batch,generated", [(2, 14, 4, True), (4, 13, 3, False), (2, 3, 4, False), (8, 12, 4, True)])
+@pytest.mark.parametrize("world,log_n,fold_batch,generated", [(2, 14, 4, True), (4, 13, 3, False), (2, 3, 4, False), (8, 12, 4, True),
+                                                             (2, 14, None, True), (2, 13, 7, False)])
 def test_sharded_ranks_on_one_gpu_gloo(tmp_path, world, log_n, fold_batch, generated):
     mp.spawn(_worker, args=(world, _free_port(), "gloo", log_n, fold_batch, generated, str(tmp_path)), nprocs=world, join=True)
     _check(tmp_path, world, log_n)

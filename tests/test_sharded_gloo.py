@@ -74,7 +74,7 @@ def _worker(rank, world, port, log_n, fold_batch, outdir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,log_n,fold_batch", [(2, 10, 4), (2, 6, 3), (4, 9, 4), (2, 2, 4), (4, 3, 1)])
+@pytest.mark.parametrize("world,log_n,fold_batch", [(2, 10, 4), (2, 6, 3), (4, 9, 4), (2, 2, 4), (4, 3, 1), (2, 10, 8), (2, 9, None)])
 def test_sharded_round_loop_matches_unsharded_oracle(tmp_path, world, log_n, fold_batch):
     port = _free_port()
     mp.spawn(_worker, args=(world, port, log_n, fold_batch, str(tmp_path)), nprocs=world, join=True)

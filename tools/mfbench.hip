@@ -128,7 +128,7 @@ int main(int argc, char** argv) {
     CHK(hipMalloc(&src, n * 32));
     CHK(hipMalloc(&dst, n * 32)); // sized for the widest ablation (1 stream: as many outputs as inputs)
     CHK(hipMalloc(&part, 2048 * 3 * 32));
-    CHK(hipMalloc(&sums, 16 * 32));
+    CHK(hipMalloc(&sums, 256 * 32)); // up to 2^8 block sums
     launch_generate(src, 1, 0, 1, n, 0);
     CHK(hipDeviceSynchronize());
     hipEvent_t a, b; CHK(hipEventCreate(&a)); CHK(hipEventCreate(&b));
@@ -166,6 +166,14 @@ int main(int argc, char** argv) {
     RUN2(16, 8, 6, Lout, Lout, "16 streams, store sc0 sc1");
     RUN2(16, 8, 7, Lout, Lout, "16 streams, store sc0 sc1 nt");
     RUN2(16, 8, 8, Lout, Lout, "16 streams, store nt");
+    RUN2(32, 8, 0, Lout / 2, Lout / 2, "32 streams, no store");
+    RUN2(32, 8, 1, Lout / 2, Lout / 2, "32 streams, plain store");
+    RUN2(64, 8, 0, Lout / 4, Lout / 4, "64 streams, no store");
+    RUN2(64, 8, 1, Lout / 4, Lout / 4, "64 streams, plain store");
+    RUN2(64, 8, 2, Lout / 4, Lout / 4, "64 streams, nontemporal store");
+    RUN2(256, 8, 0, Lout / 16, Lout / 16, "256 streams, no store");
+    RUN2(256, 8, 1, Lout / 16, Lout / 16, "256 streams, plain store");
+    RUN2(256, 8, 2, Lout / 16, Lout / 16, "256 streams, nontemporal store");
     RUN2(8, 8, 0, 2 * Lout, 2 * Lout, "8 streams, no store");
     RUN2(8, 8, 1, 2 * Lout, 2 * Lout, "8 streams, plain store");
     RUN2(4, 4, 0, 4 * Lout, 4 * Lout, "4 streams, no store");
@@ -184,6 +192,20 @@ int main(int argc, char** argv) {
     for (int group : {4, 2, 108, 104}) {
         float ms = timeit([&] { launch_multifold_lazy(4, group, src, dst, Lout, w28, 4, part, sums, 0); }, a, b);
         printf("real launch_multifold_lazy group %3d: %8.1f GB/s (%.3f ms)\n", group, bytes / ms / 1e6, ms);
+    }
+    for (int m : {5, 6, 7, 8}) {
+        uint64_t r[4 * 8], two24[4] = {1u << 24, 0, 0, 0}; // any values below p: timing only
+        for (int i = 0; i < 32; ++i) r[i] = 0x0123456789abcdefull >> (i % 4 == 3 ? 8 : 0);
+        const size_t lo = n >> m;
+        for (int log_ob : {4, 8}) {
+            float ms = timeit([&] { launch_multifold_wide(m, src, dst, lo, r, two24, log_ob, part, sums, 0); }, a, b);
+            printf("real launch_multifold_wide m = %d (%3d streams), %3d output blocks: %8.1f GB/s (%.3f ms)\n", m, 1 << m, 1 << log_ob,
+                   ((double)n * 32 + (double)lo * 32) / ms / 1e6, ms);
+        }
+    }
+    {
+        float ms = timeit([&] { launch_block_sums(src, n, 8, part, sums, 0); }, a, b);
+        printf("block_sums, 256 blocks: %8.1f GB/s (%.3f ms)\n", (double)n * 32 / ms / 1e6, ms);
     }
     {
         float ms = timeit([&] { launch_block_sums(src, n, 4, part, sums, 0); }, a, b);

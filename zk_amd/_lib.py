@@ -67,6 +67,7 @@ SYMBOLS = [
     ("zk_shard_begin", C.c_int, [_VP, _VP, C.POINTER(_VP)]),
     ("zk_shard_end", None, [_VP]),
     ("zk_shard_vars_left", C.c_int, [_VP]),
+    ("zk_shard_next_batch", C.c_int, [_VP, C.c_int]),
     ("zk_shard_block_sums", C.c_int, [_VP, C.c_int, _VP]),
     ("zk_shard_fold", C.c_int, [_VP, C.c_int, u64p, C.c_int, _VP]),
     ("zk_shard4_begin", C.c_int, [_VP, C.POINTER(_VP), C.POINTER(_VP)]),
@@ -91,6 +92,7 @@ SYMBOLS = [
     ("zk_gkr_prove", C.c_int, [_VP, _VP, _VP, _VP, u64p, u64p, u64p, u64p, C.POINTER(C.c_double)]),
     ("zk_gkr_verify", C.c_int, [_VP, _VP, _VP, _VP, u64p, C.c_size_t, u64p, u64p, u64p, C.POINTER(C.c_int)]),
     ("zk_ctx_set_fold_batch", C.c_int, [_VP, C.c_int, C.c_int]),
+    ("zk_ctx_set_wide_fold", C.c_int, [_VP, C.c_int, C.c_int]),
     ("zk_ctx_set_deg2_rounds_per_pass", C.c_int, [_VP, C.c_int]),
     ("zk_prof_enable", C.c_int, [_VP, C.c_int]),
     ("zk_prof_reset", C.c_int, [_VP]),

@@ -33,8 +33,14 @@ class Context:
 
     def set_fold_batch(self, rounds_per_pass: int, variant: int = 0):
         """Tuning knob of the single-MLE prover (proof bytes do not depend on it).
-        variant 0 = eq-weight inner product (default), 1 = fold tree, 2 = tree + double buffering."""
+        rounds_per_pass 1..8 (5..8: the wide kernel); variant 0 = eq-weight inner product (default), 1 = fold tree,
+        2 = tree + double buffering, 3..6 = load-pipelining variants of 0."""
         check(lib().zk_ctx_set_fold_batch(self.h, rounds_per_pass, variant))
+
+    def set_wide_fold(self, rounds: int = 8, min_log_out: int = 16):
+        """Passes over a large table bind `rounds` (5..8; 0 = off) variables while the folded table keeps at least
+        2^min_log_out entries.  Proof bytes do not depend on it."""
+        check(lib().zk_ctx_set_wide_fold(self.h, rounds, min_log_out))
 
     def set_deg2_rounds_per_pass(self, rounds: int):
         """Degree-2 prover schedule: 2 rounds per device pass (default) or 1.  Proof bytes do not depend on it."""

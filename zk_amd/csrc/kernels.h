@@ -14,7 +14,8 @@ namespace zkk {
 // that the second stage stays a single block (cdna_hip_programming.md, Guideline 11)
 static constexpr int kMaxBlocks = 2048;
 
-static constexpr int kMaxFoldBatch = 4; // rounds bound per pass (k_multifold<M>)
+static constexpr int kMaxFoldBatch = 8;  // rounds bound per pass (k_multifold_wide)
+static constexpr int kMaxLazyBatch = 4;  // ... by the kernel-argument-weight forms (k_multifold<M>, k_multifold_lazy<M,G>)
 // out[b] (b < 2^log_ob) = sum of the b-th contiguous block of T (L entries); partials is scratch
 int launch_block_sums(const void* T, size_t L, int log_ob, void* partials, void* out, hipStream_t st);
 // dst (Lout entries) = src (Lout << m entries) with its top m variables bound to r[0..m) (4 limbs each);
@@ -26,6 +27,9 @@ int launch_multifold(int m, const void* src, void* dst, size_t Lout, const uint6
 // group = elements per register load buffer (2 or 4)
 int launch_multifold_lazy(int m, int group, const void* src, void* dst, size_t Lout, const uint32_t* w28, int log_ob, void* partials,
                           void* out, hipStream_t st);
+// the same pass for 3 <= m <= kMaxFoldBatch: weights derived on the device from the challenges r[0..m); two24 = 2^24 (Montgomery)
+int launch_multifold_wide(int m, const void* src, void* dst, size_t Lout, const uint64_t* r, const uint64_t two24[4], int log_ob,
+                          void* partials, void* out, hipStream_t st);
 void launch_fold_var(const void* src, void* dst, size_t n_out, int log_s, const uint64_t r[4], hipStream_t st);
 void launch_reduce_partials(const void* partials, int nblocks, int ns, void* out, hipStream_t st);
 int launch_sum_all(const void* T, size_t n, void* partials, hipStream_t st);

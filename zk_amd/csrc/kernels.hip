@@ -268,6 +268,98 @@ __global__ void __launch_bounds__(kThreads) k_multifold_roll(const fq* __restric
     block_sum_store<1>(acc1, partials);
 }
 
+// Wide form of the same pass for 2^m = 8 .. 256 read streams (m up to kMaxFoldBatch).  The stores of a fold
+// pass cost the same ~20 % of the HBM rate whether they are 1/2 or 1/16 of the traffic (tools/mfbench,
+// profiles/r01_mfbench_fold_pass_ablation.txt); only at 1/256 does the pass run at the read-only rate, so the
+// first pass over a large table binds eight variables.  2^m x 10 weight limbs no longer fit in kernel
+// arguments: every workgroup derives them from the m challenges into LDS (m + 1 dependent products), the
+// group loop stays rolled (its body is 8 inner products) and reads the weights as LDS broadcasts, and the
+// columns are carried once per loop trip so that they stay below 2^64 however many products are summed.
+struct ChalWide {
+    fq r[kMaxFoldBatch];
+    fq two24; // 2^24 in Montgomery form: eq * 2^256 -> eq * 2^280 (fq28_redc divides by 2^280)
+};
+
+__global__ void __launch_bounds__(kThreads) k_multifold_wide(const fq* __restrict__ src, fq* __restrict__ dst, size_t Lout, ChalWide ch, int m,
+                                                              int log_ob, fq* __restrict__ partials) {
+    constexpr int G = 4;
+    __shared__ fq eq[1 << kMaxFoldBatch];
+    __shared__ u32 wl[(1 << kMaxFoldBatch) * 10];
+    const int nb = 1 << m, ng = nb / G; // m >= 3: ng is even
+    if (threadIdx.x == 0) {
+        const fq one = {FQ_R_LIMBS};
+        eq[0] = one;
+    }
+    __syncthreads();
+    // eq(r, b), challenge l on bit m-1-l of b: level l appends variable l as the new least significant bit
+#pragma unroll
+    for (int l = 0; l < kMaxFoldBatch; ++l) {
+        if (l < m) {
+            const bool act = (int)threadIdx.x < (1 << l);
+            fq v, hi;
+            if (act) {
+                v = eq[threadIdx.x];
+                hi = fq_mul(v, ch.r[l]);
+            }
+            __syncthreads();
+            if (act) {
+                eq[2 * threadIdx.x + 1] = hi;
+                eq[2 * threadIdx.x] = fq_sub(v, hi);
+            }
+            __syncthreads();
+        }
+    }
+    if ((int)threadIdx.x < nb) {
+        u32 l28[10];
+        fq28_unpack(fq_mul(eq[threadIdx.x], ch.two24), l28);
+#pragma unroll
+        for (int j = 0; j < 10; ++j) wl[threadIdx.x * 10 + j] = l28[j];
+    }
+    __syncthreads();
+
+    const unsigned gpb = gridDim.x >> log_ob;
+    const unsigned c = blockIdx.x / gpb, wi = blockIdx.x % gpb;
+    const size_t Lb = Lout >> log_ob;
+    const size_t j0 = (size_t)c * Lb;
+    const size_t stride = (size_t)gpb * kThreads;
+    const size_t gstep = (size_t)G * Lout;
+    fq acc1[1] = {fq_zero()};
+    const bool big = Lout >= ((size_t)1 << 22);
+    size_t i = (size_t)wi * kThreads + threadIdx.x;
+    fq A[G], B[G];
+    if (i < Lb) lazy_load<G>(A, src, Lout, j0 + i, 0);
+    while (i < Lb) {
+        const size_t n = i + stride;
+        u64 acc[20];
+#pragma unroll
+        for (int k = 0; k < 20; ++k) acc[k] = 0;
+        const fq* __restrict__ p = src + j0 + i;
+        const u32* w = wl;
+        for (int g = 0; g < ng; g += 2) {
+            lazy_load<G>(B, p + gstep, Lout, 0, 0);
+#pragma unroll
+            for (int b = 0; b < G; ++b) fq28_mac(acc, A[b], w + b * 10);
+            if (g + 2 < ng) lazy_load<G>(A, p + 2 * gstep, Lout, 0, 0);
+            else if (n < Lb) lazy_load<G>(A, src, Lout, j0 + n, 0);
+#pragma unroll
+            for (int b = 0; b < G; ++b) fq28_mac(acc, B[b], w + (G + b) * 10);
+            // carry: every column back below 2^28 (the top one keeps the overflow, which is tiny: the sum is < 2^8 p^2)
+#pragma unroll
+            for (int k = 0; k < 19; ++k) {
+                acc[k + 1] += acc[k] >> 28;
+                acc[k] &= FQ28_MASK;
+            }
+            p += 2 * gstep;
+            w += 2 * G * 10;
+        }
+        fq o = fq28_redc(acc);
+        if (big) fq_store_stream(dst + j0 + i, o); else fq_store(dst + j0 + i, o);
+        acc1[0] = fq_add(acc1[0], o);
+        i = n;
+    }
+    block_sum_store<1>(acc1, partials);
+}
+
 // second stage for the kernels above: out[c] = sum of the gpb partials of block c (fixed order)
 __global__ void __launch_bounds__(kThreads) k_reduce_groups(const fq* __restrict__ partials, int gpb, fq* __restrict__ out) {
     fq acc[1] = {fq_zero()};
@@ -625,6 +717,17 @@ int launch_multifold_lazy(int m, int group, const void* src, void* dst, size_t L
                        : launch_multifold_lazy_m<4, 4>(src, dst, Lout, w28, log_ob, partials, st); break;
         default: return -1;
     }
+    hipLaunchKernelGGL(k_reduce_groups, dim3(1 << log_ob), dim3(kThreads), 0, st, (const fq*)partials, g >> log_ob, (fq*)out);
+    return g;
+}
+int launch_multifold_wide(int m, const void* src, void* dst, size_t Lout, const uint64_t* r, const uint64_t two24[4], int log_ob,
+                          void* partials, void* out, hipStream_t st) {
+    if (m < 3 || m > kMaxFoldBatch) return -1;
+    ChalWide ch;
+    for (int l = 0; l < kMaxFoldBatch; ++l) ch.r[l] = l < m ? to_fq(r + 4 * l) : fq{};
+    ch.two24 = to_fq(two24);
+    int g = grid_blocks(Lout >> log_ob, log_ob);
+    hipLaunchKernelGGL(k_multifold_wide, dim3(g), dim3(kThreads), 0, st, (const fq*)src, (fq*)dst, Lout, ch, m, log_ob, (fq*)partials);
     hipLaunchKernelGGL(k_reduce_groups, dim3(1 << log_ob), dim3(kThreads), 0, st, (const fq*)partials, g >> log_ob, (fq*)out);
     return g;
 }

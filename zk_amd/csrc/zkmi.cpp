@@ -299,7 +299,7 @@ int zk_mle_evaluate(const zk_mle* m, const uint8_t* has, const uint64_t* vals, s
     if (pre >= 2) {
         zk_shard st{c, m->d, (unsigned)npts, 0};
         while (first < pre) {
-            const int mm = (int)std::min<size_t>(zkk::kMaxFoldBatch, pre - first);
+            const int mm = (int)std::min<size_t>(next_batch(c, st.ell), pre - first);
             if ((rc = zk_shard_fold(&st, mm, vals + 4 * first, 0, nullptr))) return rc;
             first += (size_t)mm;
         }
@@ -434,6 +434,11 @@ int zk_shard_begin(zk_ctx* c, const zk_mle* local, zk_shard** out) {
 void zk_shard_end(zk_shard* s) { delete s; }
 int zk_shard_vars_left(const zk_shard* s) { return s ? (int)s->ell : -1; }
 
+int zk_shard_next_batch(const zk_shard* s, int after_binding) {
+    if (!s || after_binding < 0 || (unsigned)after_binding > s->ell) return -1;
+    return (int)next_batch(s->ctx, s->ell - (unsigned)after_binding);
+}
+
 // sums_dev_out[b] (b < 2^m) = sum of the b-th contiguous block of the current local table; asynchronous
 int zk_shard_block_sums(zk_shard* s, int m, void* sums_dev_out) {
     if (!s || !sums_dev_out || m < 1 || m > zkk::kMaxFoldBatch || (unsigned)m > s->ell) return ZK_E_ARG;
@@ -465,8 +470,12 @@ int zk_shard_fold(zk_shard* s, int m, const uint64_t* r_mont, int m_next, void* 
     void* sums = m_next ? sums_dev_out : c->sums_dev;
     {
         ProfScope ps(c, ZK_K_MULTIFOLD, (uint64_t)(lout << m) * 32 + (uint64_t)lout * 32);
-        if (c->lazy && m >= 2) {
-            uint32_t w28[(1 << zkk::kMaxFoldBatch) * 10];
+        if (m > zkk::kMaxLazyBatch) {
+            uint64_t two24[4];
+            zkh::store(two24, zkh::from_u64((uint64_t)1 << 24));
+            zkk::launch_multifold_wide(m, s->cur, dst, lout, r_mont, two24, m_next, c->partials, sums, c->stream);
+        } else if (c->lazy && m >= 2) {
+            uint32_t w28[(1 << zkk::kMaxLazyBatch) * 10];
             eq_weights28(r_mont, (unsigned)m, w28);
             zkk::launch_multifold_lazy(m, c->lazy_group, s->cur, dst, lout, w28, m_next, c->partials, sums, c->stream);
         } else {
@@ -504,9 +513,8 @@ int zk_sumcheck_prove_mle(zk_ctx* c, const zk_mle* poly, int absorb_table, zk_tr
         return ZK_OK;
     }
 
-    const unsigned M = (unsigned)c->fold_batch;
     zk_shard st{c, poly->d, n, 0};
-    unsigned m = std::min(M, st.ell), k = 0;
+    unsigned m = next_batch(c, st.ell), k = 0;
     if ((rc = zk_shard_block_sums(&st, (int)m, c->sums_host_dev))) return rc; // sums land in pinned host memory
     for (;;) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -515,7 +523,7 @@ int zk_sumcheck_prove_mle(zk_ctx* c, const zk_mle* poly, int absorb_table, zk_tr
         if (challenges_out) std::memcpy(challenges_out + 4 * k, rs, (size_t)m * kElem);
         k += m;
         if (st.ell == m) break; // the fully folded table (one entry) is never used by the prover
-        const unsigned m_next = std::min(M, st.ell - m);
+        const unsigned m_next = next_batch(c, st.ell - m);
         if ((rc = zk_shard_fold(&st, (int)m, rs, (int)m_next, c->sums_host_dev))) return rc;
         m = m_next;
     }
@@ -905,6 +913,12 @@ int zk_ctx_set_fold_batch(zk_ctx* c, int rounds_per_pass, int variant) {
     c->lazy = variant == 0 || variant >= 3;
     c->lazy_group = variant == 3 ? 2 : variant == 4 ? 108 : variant == 5 ? 104 : variant == 6 ? 116 : 4;
     c->double_buffer = variant == 2;
+    return ZK_OK;
+}
+int zk_ctx_set_wide_fold(zk_ctx* c, int rounds, int min_log_out) {
+    if (!c || (rounds != 0 && (rounds <= zkk::kMaxLazyBatch || rounds > zkk::kMaxFoldBatch)) || min_log_out < 0 || min_log_out > 40) return ZK_E_ARG;
+    c->wide_batch = rounds;
+    c->wide_min_log_out = min_log_out;
     return ZK_OK;
 }
 int zk_ctx_set_deg2_rounds_per_pass(zk_ctx* c, int rounds) {

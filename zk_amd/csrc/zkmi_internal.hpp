@@ -22,9 +22,10 @@ using zkh::Fq;
 namespace zki {
 constexpr size_t kElem = 32;
 constexpr size_t kChunkElems = (size_t)1 << 21; // 64 MiB staging chunks for byte conversion
-constexpr size_t kSums = 16;                    // 2^kMaxFoldBatch block sums per pass
+constexpr size_t kSums = (size_t)1 << zkk::kMaxFoldBatch; // block sums per pass
 constexpr size_t kHostTail = 64;                // degree-2 prover: tables of <= this many entries are finished on the host
 constexpr size_t kHostStage = 4 * kHostTail;    // elements of the pinned staging buffer
+static_assert(kHostStage >= kSums, "the staging buffer also receives the block sums of a pass");
 
 inline bool is_pow2(size_t n) { return n && !(n & (n - 1)); }
 inline unsigned ilog2(size_t n) {
@@ -62,6 +63,8 @@ struct zk_ctx {
     uint64_t* sums_host = nullptr; // pinned + device-mapped, kHostStage elements: kernels write small results here directly
     void* sums_host_dev = nullptr; // the device address of sums_host
     int fold_batch = 4;          // rounds bound per device pass (1..kMaxFoldBatch)
+    int wide_batch = 8;          // rounds bound by a pass over a LARGE table (0: never; kernels.hip, k_multifold_wide) ...
+    int wide_min_log_out = 16;   // ... taken while its output keeps at least 2^wide_min_log_out entries
     bool double_buffer = false;  // register double-buffering in k_multifold (tree variant)
     bool lazy = true;            // inner-product form with one reduction per output (k_multifold_lazy)
     bool deg2_pairs = true;      // degree-2 prover: two rounds per device pass (k_sum9 / k_fold2x4_sum9)
@@ -106,6 +109,18 @@ struct zk_shard {
 namespace zki {
 
 inline int set_device(zk_ctx* c) { HIPCHK(c, hipSetDevice(c->device)); return ZK_OK; }
+
+// rounds the next pass over a local table of `ell` variables should bind: as many as the wide batch allows while
+// the folded table keeps 2^wide_min_log_out entries (below that the chip is short of independent outputs and the
+// pass turns latency-bound) if that beats the default batch by two rounds or more (measured: tools/wide_sweep.sh),
+// the default batch otherwise
+inline unsigned next_batch(const zk_ctx* c, unsigned ell) {
+    if (c->wide_batch > c->fold_batch && ell > (unsigned)c->wide_min_log_out) {
+        const unsigned w = std::min((unsigned)c->wide_batch, ell - (unsigned)c->wide_min_log_out);
+        if (w >= (unsigned)c->fold_batch + 2 || w == (unsigned)c->wide_batch) return w;
+    }
+    return std::min((unsigned)c->fold_batch, ell);
+}
 
 inline int ensure_work(zk_ctx* c, int which, size_t bytes) {
     if (c->work_cap[which] >= bytes) return ZK_OK;
@@ -180,7 +195,7 @@ inline int fetch_block_sums(zk_ctx* c, int ns, Fq* out) {
 // eq(r, b) * 2^280 mod p for all b < 2^m as 10 x 28-bit limbs each; r[l] (Montgomery, 4 limbs each)
 // belongs to bit (m-1-l) of b: variable 0 is the most significant index bit (evaluation_form.rs:40-42)
 inline void eq_weights28(const uint64_t* rs, unsigned m, uint32_t* w28) {
-    Fq eq[1 << zkk::kMaxFoldBatch];
+    Fq eq[1 << zkk::kMaxLazyBatch];
     eq[0] = zkh::one();
     unsigned n = 1;
     for (unsigned l = 0; l < m; ++l) { // append variable l as the new least significant bit

@@ -25,7 +25,8 @@ from .context import Context
 from .polynomials import MultiLinearPolynomial
 from .transcript import Transcript
 
-MAX_FOLD_BATCH = 4
+MAX_FOLD_BATCH = 8      # rounds one device pass can bind (zkk::kMaxFoldBatch)
+DEFAULT_FOLD_BATCH = 4  # schedule of shards that do not bring their own (zk_shard_next_batch)
 
 
 def _ptr(a: np.ndarray):
@@ -66,6 +67,11 @@ class DeviceShard:
 
     def vars_left(self) -> int:
         return lib().zk_shard_vars_left(self.h)
+
+    def next_batch(self, after_binding: int = 0) -> int:
+        """Rounds a pass should bind once `after_binding` more variables are bound (the context's schedule:
+        wide passes while the table is large)."""
+        return lib().zk_shard_next_batch(self.h, after_binding)
 
     def new_sums(self, count: int):
         return self._torch.empty((count, 4), dtype=self._torch.int64, device=self._torch.device("cuda", self.ctx.device_id))
@@ -108,9 +114,11 @@ def gather_sums(local, world: int, dist=None, group=None) -> np.ndarray:
 
 
 def generate_round_polys_sharded(shard, transcript: Transcript, world: int, dist=None, group=None,
-                                 fold_batch: int = MAX_FOLD_BATCH):
+                                 fold_batch: int | None = None):
     """generate_round_polys (sumcheck/src/prover.rs:45-155, MLE branch) for a sharded table.
-    Every rank returns the same (claim (4,), round_polys (n,2,4), challenges (n,4))."""
+    Every rank returns the same (claim (4,), round_polys (n,2,4), challenges (n,4)).
+    fold_batch: rounds per device pass; None = the shard's own schedule (DeviceShard.next_batch), which only
+    depends on the local table size and the context settings, i.e. is the same on every rank."""
     g = world.bit_length() - 1
     if world != 1 << g:
         raise ValueError("world size must be a power of two")
@@ -118,12 +126,17 @@ def generate_round_polys_sharded(shard, transcript: Transcript, world: int, dist
     if ell < 1:
         raise ValueError("each rank needs at least 2 local entries")
     n = ell + g
-    M = max(1, min(fold_batch, MAX_FOLD_BATCH))
+    own = fold_batch is None and hasattr(shard, "next_batch")
+    M = max(1, min(fold_batch or DEFAULT_FOLD_BATCH, MAX_FOLD_BATCH))
+
+    def batch(left: int, after_binding: int) -> int:
+        return shard.next_batch(after_binding) if own else min(M, left)
+
     coeffs = np.empty((n, 2, 4), dtype=np.uint64)
     ch = np.empty((n, 4), dtype=np.uint64)
     claim = None
-    buf = shard.new_sums(1 << M)
-    m, k = min(M, ell), 0
+    buf = shard.new_sums(1 << MAX_FOLD_BATCH)
+    m, k = batch(ell, 0), 0
     shard.block_sums(m, buf)
     while True:
         sums = gather_sums(buf[: 1 << m], world, dist, group)
@@ -135,7 +148,7 @@ def generate_round_polys_sharded(shard, transcript: Transcript, world: int, dist
         k += m
         if last:
             break
-        m_next = min(M, ell - m)
+        m_next = batch(ell - m, m)
         shard.fold(m, r, m_next, buf)
         ell -= m
         m = m_next
