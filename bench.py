@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--wide-min-log-out", type=int, default=16, help="wide passes are taken while the folded table keeps >= 2^k entries")
     ap.add_argument("--fold-variant", type=int, default=0, help="0 eq-weight inner product, 1 tree, 2 tree+double buffer")
     ap.add_argument("--deg2-rounds", type=int, default=0, help="degree-2 prover: rounds per device pass (1 or 2; 0 = library default, 2)")
+    ap.add_argument("--gather-log", type=int, default=13, help="multi-GPU: local tables of <= 2^k entries are all-gathered and finished on every rank (-1 = sharded to the end)")
     ap.add_argument("--weak", action="store_true", help="multi-GPU: 2^log_n entries PER GPU instead of in total")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for the multi-GPU exchange")
     ap.add_argument("--shared-device", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
@@ -288,6 +289,7 @@ def bench_sharded(args, zk_amd, np, dist, rank, local_rank, world):
         ctx.set_fold_batch(args.fold_batch, args.fold_variant)
     if args.wide_batch >= 0:
         ctx.set_wide_fold(args.wide_batch, args.wide_min_log_out)
+    gather_log = args.gather_log if args.gather_log >= 0 else None
     fold_batch = None  # the library's schedule (zk_shard_next_batch): the same passes as the single-GPU prover
     base = zk_amd.Transcript()
     base.append(b"bench: table absorb skipped (sharded run; SURVEY.md H1)")
@@ -297,13 +299,13 @@ def bench_sharded(args, zk_amd, np, dist, rank, local_rank, world):
         def step():
             sh = sharded.DeviceShard(poly)
             try:
-                return sharded.generate_round_polys_sharded(sh, base.clone(), world, dist, None, fold_batch)
+                return sharded.generate_round_polys_sharded(sh, base.clone(), world, dist, None, fold_batch, gather_log)
             finally:
                 sh.close()
 
         dom_kernel, names = "multifold", ("block_sums", "multifold")
         what = f"single-MLE sumcheck, 2^{log_total} entries"
-        exchange = f"all-gather of 2^m block sums per pass ({dist.get_backend()}), library pass schedule"
+        exchange = f"all-gather of 2^m block sums per pass ({dist.get_backend()}), library pass schedule; tables of <= 2^{args.gather_log} entries per rank all-gathered and finished on every rank"
     else:
         tabs = [zk_amd.MultiLinearPolynomial.generate(SEED + k, n_local, first=rank, step=world, ctx=ctx) for k in range(4)]
 

@@ -155,6 +155,11 @@ int zk_shard_vars_left(const zk_shard *s);
  * zk_ctx_set_wide_fold).  Any m <= vars_left is valid for zk_shard_block_sums / zk_shard_fold; this is the
  * schedule zk_sumcheck_prove_mle uses.  0 when no variable is left, -1 on a bad argument. */
 int zk_shard_next_batch(const zk_shard *s, int after_binding);
+/* dst_dev (device, 2^vars_left elements) = the current local table (asynchronous).  For the switch from sharded
+ * passes to replicated ones: once the local tables are small, the ranks all-gather them (entry j of rank q is
+ * entry j*world + q of the remaining table) and every rank finishes with zk_sumcheck_prove_mle(absorb_table = 0)
+ * on the gathered table and the running transcript -- no further exchange. */
+int zk_shard_copy_table(zk_shard *s, void *dst_dev);
 /* sums_dev_out (device, 2^m elements) = sums of the 2^m contiguous blocks of the current local table */
 int zk_shard_block_sums(zk_shard *s, int m, void *sums_dev_out);
 /* bind the top m variables at r[0..m) (m x partially_evaluate((0, r)), evaluation_form.rs:163-192) and

@@ -27,7 +27,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, backend, log_n, fold_batch, generated, outdir):
+def _worker(rank, world, port, backend, log_n, fold_batch, generated, outdir, gather_log=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.cuda.set_device(0)
     if backend == "nccl":
@@ -46,7 +46,7 @@ def _worker(rank, world, port, backend, log_n, fold_batch, generated, outdir):
         tr = zk_amd.Transcript()
         sharded.absorb_table_sharded(local, tr, world, dist, None, chunk=1 << 8)
         sh = sharded.DeviceShard(local)
-        claim, coeffs, ch = sharded.generate_round_polys_sharded(sh, tr, world, dist, None, fold_batch)
+        claim, coeffs, ch = sharded.generate_round_polys_sharded(sh, tr, world, dist, None, fold_batch, gather_log)
         sh.close()
         np.savez(os.path.join(outdir, f"r{rank}.npz"), claim=claim, coeffs=coeffs, ch=ch)
     finally:
@@ -68,6 +68,17 @@ def _check(tmp_path, world, log_n):
 def test_sharded_ranks_on_one_gpu_gloo(tmp_path, world, log_n, fold_batch, generated):
     mp.spawn(_worker, args=(world, _free_port(), "gloo", log_n, fold_batch, generated, str(tmp_path)), nprocs=world, join=True)
     _check(tmp_path, world, log_n)
+
+
+@pytest.mark.parametrize("world,log_n,fold_batch,gather_log", [(2, 14, 4, 6), (4, 13, None, 13), (8, 12, 4, 3), (2, 15, None, 9)])
+def test_sharded_ranks_gather_small_tables_and_finish_replicated(tmp_path, world, log_n, fold_batch, gather_log):
+    mp.spawn(_worker, args=(world, _free_port(), "gloo", log_n, fold_batch, True, str(tmp_path), gather_log), nprocs=world, join=True)
+    _check(tmp_path, world, log_n)
+
+
+def test_single_rank_rccl_with_table_gather(tmp_path):
+    mp.spawn(_worker, args=(1, _free_port(), "nccl", 12, None, True, str(tmp_path), 7), nprocs=1, join=True)
+    _check(tmp_path, 1, 12)
 
 
 def test_single_rank_through_rccl_backend(tmp_path):

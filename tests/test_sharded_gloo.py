@@ -52,6 +52,16 @@ class OracleShard:
         if m_next:
             self._sums(m_next, out)
 
+    def table(self):
+        return torch.from_numpy(self.t.view(np.int64).copy())
+
+    def finish(self, table, transcript):
+        """the remaining table on one rank: libzkmi's host round function on the table itself (world 1, sums =
+        entries) is the whole round loop"""
+        t = table.numpy().view(np.uint64).reshape(1, -1, 4)
+        coeffs, ch, _, total = sharded.rounds_from_block_sums(transcript, t, want_total=True)
+        return total, coeffs, ch
+
 
 def _free_port():
     with socket.socket() as s:
@@ -59,7 +69,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, log_n, fold_batch, outdir):
+def _worker(rank, world, port, log_n, fold_batch, gather_log, outdir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -68,16 +78,19 @@ def _worker(rank, world, port, log_n, fold_batch, outdir):
         local = table[rank::world]  # entry j of the shard = global entry j*world + rank
         tr = zk_amd.Transcript()
         tr.append(O.mle_to_bytes(table))  # generate_sumcheck_proof absorbs the whole table first
-        claim, coeffs, ch = sharded.generate_round_polys_sharded(OracleShard(local), tr, world, dist, None, fold_batch)
+        claim, coeffs, ch = sharded.generate_round_polys_sharded(OracleShard(local), tr, world, dist, None, fold_batch, gather_log)
         np.savez(os.path.join(outdir, f"r{rank}.npz"), claim=claim, coeffs=coeffs, ch=ch, digest=np.frombuffer(tr.peek_digest(), dtype=np.uint8))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,log_n,fold_batch", [(2, 10, 4), (2, 6, 3), (4, 9, 4), (2, 2, 4), (4, 3, 1), (2, 10, 8), (2, 9, None)])
-def test_sharded_round_loop_matches_unsharded_oracle(tmp_path, world, log_n, fold_batch):
+@pytest.mark.parametrize("world,log_n,fold_batch,gather_log", [
+    (2, 10, 4, None), (2, 6, 3, None), (4, 9, 4, None), (2, 2, 4, None), (4, 3, 1, None), (2, 10, 8, None), (2, 9, None, None),
+    # switch to replicated passes once the local tables are down to 2^gather_log entries
+    (2, 10, 4, 5), (4, 9, 3, 2), (2, 8, 4, 0), (2, 6, 4, 13), (4, 7, 8, 4), (2, 1, 4, 13)])
+def test_sharded_round_loop_matches_unsharded_oracle(tmp_path, world, log_n, fold_batch, gather_log):
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, log_n, fold_batch, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, log_n, fold_batch, gather_log, str(tmp_path)), nprocs=world, join=True)
     table = O.gen_table(SEED, 0, 1 << log_n)
     oclaim, ocoeffs, och = O.sumcheck_prove(table)
     digests = []

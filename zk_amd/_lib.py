@@ -68,6 +68,7 @@ SYMBOLS = [
     ("zk_shard_end", None, [_VP]),
     ("zk_shard_vars_left", C.c_int, [_VP]),
     ("zk_shard_next_batch", C.c_int, [_VP, C.c_int]),
+    ("zk_shard_copy_table", C.c_int, [_VP, _VP]),
     ("zk_shard_block_sums", C.c_int, [_VP, C.c_int, _VP]),
     ("zk_shard_fold", C.c_int, [_VP, C.c_int, u64p, C.c_int, _VP]),
     ("zk_shard4_begin", C.c_int, [_VP, C.POINTER(_VP), C.POINTER(_VP)]),

@@ -439,6 +439,16 @@ int zk_shard_next_batch(const zk_shard* s, int after_binding) {
     return (int)next_batch(s->ctx, s->ell - (unsigned)after_binding);
 }
 
+// dst_dev (2^vars_left elements) = the current local table; asynchronous on the context stream
+int zk_shard_copy_table(zk_shard* s, void* dst_dev) {
+    if (!s || !dst_dev) return ZK_E_ARG;
+    zk_ctx* c = s->ctx;
+    int rc = set_device(c);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(dst_dev, s->cur, ((size_t)1 << s->ell) * kElem, hipMemcpyDeviceToDevice, c->stream));
+    return ZK_OK;
+}
+
 // sums_dev_out[b] (b < 2^m) = sum of the b-th contiguous block of the current local table; asynchronous
 int zk_shard_block_sums(zk_shard* s, int m, void* sums_dev_out) {
     if (!s || !sums_dev_out || m < 1 || m > zkk::kMaxFoldBatch || (unsigned)m > s->ell) return ZK_E_ARG;

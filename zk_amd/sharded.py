@@ -27,6 +27,7 @@ from .transcript import Transcript
 
 MAX_FOLD_BATCH = 8      # rounds one device pass can bind (zkk::kMaxFoldBatch)
 DEFAULT_FOLD_BATCH = 4  # schedule of shards that do not bring their own (zk_shard_next_batch)
+DEFAULT_GATHER_LOG = 13 # local tables of <= 2^13 entries (256 KiB) are all-gathered and finished on every rank
 
 
 def _ptr(a: np.ndarray):
@@ -83,6 +84,21 @@ class DeviceShard:
         r = np.ascontiguousarray(r, dtype=np.uint64)
         check(lib().zk_shard_fold(self.h, m, _ptr(r), m_next, C.c_void_p(out.data_ptr())), self.ctx.h)
 
+    def table(self):
+        """The current local table as a (2^vars_left, 4) int64 device tensor (a copy, on the context stream)."""
+        out = self._torch.empty((1 << self.vars_left(), 4), dtype=self._torch.int64,
+                                device=self._torch.device("cuda", self.ctx.device_id))
+        check(lib().zk_shard_copy_table(self.h, C.c_void_p(out.data_ptr())), self.ctx.h)
+        return out
+
+    def finish(self, table, transcript: Transcript):
+        """All remaining rounds on this GPU alone: `table` is the whole remaining table (device tensor)."""
+        from .sumcheck import SumcheckProver
+
+        table = table.contiguous()
+        poly = MultiLinearPolynomial.wrap_device(table.data_ptr(), table.shape[0], ctx=self.ctx)
+        return SumcheckProver.generate_round_polys(poly, transcript)
+
     def close(self):
         if getattr(self, "h", None):
             lib().zk_shard_end(self.h)
@@ -95,6 +111,26 @@ class DeviceShard:
             pass
 
 
+_pinned = {}
+
+
+def _to_host(t) -> np.ndarray:
+    """Device tensor -> host uint64 view through a cached pinned buffer (one async copy + one stream sync; the
+    pageable path of Tensor.cpu() stages and blocks twice).  The view is valid until the next call with the same
+    shape: callers consume it at once."""
+    import torch
+
+    if not t.is_cuda:
+        return t.contiguous().numpy().view(np.uint64)
+    key = (tuple(t.shape), t.dtype, t.device.index)
+    h = _pinned.get(key)
+    if h is None:
+        h = _pinned[key] = torch.empty(tuple(t.shape), dtype=t.dtype, pin_memory=True)
+    h.copy_(t, non_blocking=True)
+    torch.cuda.current_stream(t.device).synchronize()
+    return h.numpy().view(np.uint64)
+
+
 def gather_sums(local, world: int, dist=None, group=None) -> np.ndarray:
     """all-gather of one (k,4) int64 tensor per rank -> (world, k, 4) uint64 on the host.
     nccl: the collective runs on the device tensors (RCCL), one D2H of the gathered block;
@@ -102,38 +138,68 @@ def gather_sums(local, world: int, dist=None, group=None) -> np.ndarray:
     import torch
 
     if world == 1 or dist is None:
-        return local.cpu().numpy().view(np.uint64)[None]
+        return _to_host(local)[None]
     if dist.get_backend(group) == "nccl":
         out = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
         dist.all_gather_into_tensor(out, local.contiguous(), group=group)
-        return out.cpu().numpy().view(np.uint64)
+        return _to_host(out)
     host = local.cpu().contiguous()
     parts = [torch.empty_like(host) for _ in range(world)]
     dist.all_gather(parts, host, group=group)
     return torch.stack(parts).numpy().view(np.uint64)
 
 
+def gather_tables(local, world: int, dist=None, group=None):
+    """all-gather of the ranks' local tables (2^l, 4) -> the remaining table (world * 2^l, 4), entry j*world + q =
+    rank q's entry j, on the device the local table lives on."""
+    import torch
+
+    if world == 1 or dist is None:
+        return local
+    if dist.get_backend(group) == "nccl":
+        out = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(out, local.contiguous(), group=group)
+    else:
+        host = local.cpu().contiguous()
+        parts = [torch.empty_like(host) for _ in range(world)]
+        dist.all_gather(parts, host, group=group)
+        out = torch.stack(parts).to(local.device)
+    return out.permute(1, 0, 2).contiguous().reshape(-1, 4)
+
+
 def generate_round_polys_sharded(shard, transcript: Transcript, world: int, dist=None, group=None,
-                                 fold_batch: int | None = None):
+                                 fold_batch: int | None = None, gather_log: int | None = DEFAULT_GATHER_LOG):
     """generate_round_polys (sumcheck/src/prover.rs:45-155, MLE branch) for a sharded table.
     Every rank returns the same (claim (4,), round_polys (n,2,4), challenges (n,4)).
     fold_batch: rounds per device pass; None = the shard's own schedule (DeviceShard.next_batch), which only
-    depends on the local table size and the context settings, i.e. is the same on every rank."""
+    depends on the local table size and the context settings, i.e. is the same on every rank.
+    gather_log: once a rank's table is down to 2^gather_log entries the ranks all-gather their tables and every
+    rank finishes the remaining rounds alone (replicated, no further exchange): small passes are bound by the
+    latency of the exchange, not by the work.  None: sharded to the end."""
     g = world.bit_length() - 1
     if world != 1 << g:
         raise ValueError("world size must be a power of two")
     ell = shard.vars_left()
-    if ell < 1:
-        raise ValueError("each rank needs at least 2 local entries")
     n = ell + g
     own = fold_batch is None and hasattr(shard, "next_batch")
     M = max(1, min(fold_batch or DEFAULT_FOLD_BATCH, MAX_FOLD_BATCH))
+    T = gather_log if (gather_log is not None and hasattr(shard, "finish")) else -1
 
     def batch(left: int, after_binding: int) -> int:
         return shard.next_batch(after_binding) if own else min(M, left)
 
     coeffs = np.empty((n, 2, 4), dtype=np.uint64)
     ch = np.empty((n, 4), dtype=np.uint64)
+
+    def finish_gathered(k: int, claim):
+        total, c, r = shard.finish(gather_tables(shard.table(), world, dist, group), transcript)
+        coeffs[k:], ch[k:] = c, r
+        return (total if k == 0 else claim), coeffs, ch
+
+    if ell <= T:
+        return finish_gathered(0, None)
+    if ell < 1:
+        raise ValueError("each rank needs at least 2 local entries")
     claim = None
     buf = shard.new_sums(1 << MAX_FOLD_BATCH)
     m, k = batch(ell, 0), 0
@@ -148,6 +214,9 @@ def generate_round_polys_sharded(shard, transcript: Transcript, world: int, dist
         k += m
         if last:
             break
+        if ell - m <= T:
+            shard.fold(m, r, 0, buf)
+            return finish_gathered(k, claim)
         m_next = batch(ell - m, m)
         shard.fold(m, r, m_next, buf)
         ell -= m
