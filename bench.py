@@ -312,13 +312,14 @@ def bench_sharded(args, zk_amd, np, dist, rank, local_rank, world):
         def step():
             sh = sharded.DeviceShard4(tabs)
             try:
-                return sharded.generate_round_polys_sum2x2_sharded(sh, base.clone(), world, dist, None)
+                return sharded.generate_round_polys_sum2x2_sharded(sh, base.clone(), world, dist, None, gather_log)
             finally:
                 sh.close()
 
-        dom_kernel, names = "fold4_eval3", ("eval3", "fold4_eval3")
+        dom_kernel, names = ("fold4_eval3", ("eval3", "fold4_eval3")) if gather_log is None else ("fold2x4_sum9", ("sum9", "fold2x4_sum9"))
         what = f"degree-2 sumcheck Sum[Prod[f,g],Prod[h,k]], 4 x 2^{log_total} entries"
-        exchange = f"all-gather of 3 evaluation shares per round ({dist.get_backend()})"
+        exchange = (f"all-gather of 3 evaluation shares per round ({dist.get_backend()})" if gather_log is None else
+                    f"all-gather of nine sums per two rounds ({dist.get_backend()}); tables of <= 2^{gather_log} entries per rank all-gathered and finished on every rank")
 
     for _ in range(args.warmup):
         step()

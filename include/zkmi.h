@@ -182,6 +182,21 @@ int zk_shard4_fold(zk_shard4 *s, const uint64_t r_mont[4], void *out_dev);
 /* evals: [world][3] elements; coeffs_out: the round polynomial (3 coefficients); host only */
 int zk_sumcheck_round_from_evals(zk_transcript *t, const uint64_t *evals, int world, uint64_t coeffs_out[12],
                                  uint64_t challenge_out[4]);
+/* Two rounds per exchange (the schedule zk_sumcheck_prove_sum2x2 uses on one GPU): each rank's share of the nine
+ * sums S[3Y + t] (t: f0*g0, f1*g1, df*dg with the top variable at 0 / 1 / difference; Y in {0,1,2} the value of
+ * the second variable; summed over the rest and both product terms -- linear in the entries, so shares add)
+ * determines the round polynomials of BOTH next rounds (prover.rs:89-107 twice); one 4-to-1 fold binds both.
+ *   zk_shard4_sum9: 9 elements (needs >= 4 entries per local table)
+ *   zk_sumcheck_round_pair_from_sum9: sums [world][9]; coeffs_out 2 x 3 coefficients, challenges_out 2; host only
+ *   zk_shard4_fold2: bind both at r2[0], r2[1]; sums_dev_out (may be NULL) gets the next nine sums if >= 4 entries
+ *     per table remain
+ *   zk_shard4_copy_tables: dst_dev (4 x len elements, table after table) = the current local tables, for the
+ *     switch to replicated passes (see zk_shard_copy_table); every rank then finishes with zk_sumcheck_prove_sum2x2. */
+int zk_shard4_sum9(zk_shard4 *s, void *sums_dev_out);
+int zk_sumcheck_round_pair_from_sum9(zk_transcript *t, const uint64_t *sums, int world, uint64_t coeffs_out[24],
+                                     uint64_t challenges_out[8]);
+int zk_shard4_fold2(zk_shard4 *s, const uint64_t r2_mont[8], void *sums_dev_out);
+int zk_shard4_copy_tables(zk_shard4 *s, void *dst_dev);
 /* generate_round_polys, SumPolynomial branch, on four HOST tables of len entries (4 x len elements,
  * table-major); coeffs_out log2(len) x 3, challenges_out log2(len) (may be NULL); host only */
 int zk_sumcheck_prove_sum2x2_host(zk_transcript *t, const uint64_t *tables, size_t len, uint64_t *coeffs_out,

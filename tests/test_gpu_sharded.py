@@ -122,7 +122,7 @@ def test_device_shard_steps_match_oracle():
 
 
 # ---------------------------------------------------------------- degree-2 branch, sharded
-def _worker4(rank, world, port, backend, log_n, outdir):
+def _worker4(rank, world, port, backend, log_n, gather_log, outdir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.cuda.set_device(0)
     if backend == "nccl":
@@ -136,16 +136,19 @@ def _worker4(rank, world, port, backend, log_n, outdir):
         tr = zk_amd.Transcript()
         tr.append(b"degree-2 sharded")
         sh = sharded.DeviceShard4(tabs)
-        coeffs, ch = sharded.generate_round_polys_sum2x2_sharded(sh, tr, world, dist)
+        coeffs, ch = sharded.generate_round_polys_sum2x2_sharded(sh, tr, world, dist, None, gather_log)
         sh.close()
         np.savez(os.path.join(outdir, f"q{rank}.npz"), coeffs=coeffs, ch=ch)
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,backend,log_n", [(2, "gloo", 10), (4, "gloo", 9), (2, "gloo", 2), (1, "nccl", 8)])
-def test_sharded_degree2_on_one_gpu(tmp_path, world, backend, log_n):
-    mp.spawn(_worker4, args=(world, _free_port(), backend, log_n, str(tmp_path)), nprocs=world, join=True)
+@pytest.mark.parametrize("world,backend,log_n,gather_log", [
+    (2, "gloo", 10, None), (4, "gloo", 9, None), (2, "gloo", 2, None), (1, "nccl", 8, None),
+    # two rounds per exchange, then gathered tables finished on every rank
+    (2, "gloo", 12, 4), (4, "gloo", 11, 1), (8, "gloo", 12, 3), (2, "gloo", 9, 13), (1, "nccl", 10, 5), (2, "gloo", 13, 7)])
+def test_sharded_degree2_on_one_gpu(tmp_path, world, backend, log_n, gather_log):
+    mp.spawn(_worker4, args=(world, _free_port(), backend, log_n, gather_log, str(tmp_path)), nprocs=world, join=True)
     tabs = [O.gen_table(SEED + 10 + k, 0, 1 << log_n) for k in range(4)]
     otr = O.OTranscript()
     otr.append(b"degree-2 sharded")

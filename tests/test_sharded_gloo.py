@@ -165,7 +165,42 @@ class OracleShard4:
             self._put([t[0] for t in self.t], out)
 
 
-def _worker4(rank, world, port, log_n, outdir):
+    # two rounds per exchange
+    def new_buf9(self):
+        return torch.zeros((9, 4), dtype=torch.int64)
+
+    def sum9(self, out):
+        """S[3Y + t]: the table index is (b1, b2, j); F(b1, Y) = F[b1,0] + Y (F[b1,1] - F[b1,0]); f0 = F(0,Y), f1 = F(1,Y),
+        df = f1 - f0; t = 0: f0 g0, 1: f1 g1, 2: df dg; summed over j and both product terms (kernels.hip, k_sum9)"""
+        q = len(self.t[0]) // 4
+        S = [0] * 9
+        for j in range(q):
+            for Y in range(3):
+                at = lambda t, b1: (t[b1 * 2 * q + j] + Y * (t[b1 * 2 * q + q + j] - t[b1 * 2 * q + j])) % P
+                for F, G in ((self.t[0], self.t[1]), (self.t[2], self.t[3])):
+                    f0, f1, g0, g1 = at(F, 0), at(F, 1), at(G, 0), at(G, 1)
+                    S[3 * Y] = (S[3 * Y] + f0 * g0) % P
+                    S[3 * Y + 1] = (S[3 * Y + 1] + f1 * g1) % P
+                    S[3 * Y + 2] = (S[3 * Y + 2] + (f1 - f0) * (g1 - g0)) % P
+        self._put(S, out)
+
+    def fold2(self, r2, out):
+        for r in np.asarray(r2).reshape(2, 4):
+            rr = O.mont_to_ints(r.reshape(1, 4))[0]
+            h = len(self.t[0]) // 2
+            self.t = [[(t[j] + (t[j + h] - t[j]) * rr) % P for j in range(h)] for t in self.t]
+        if out is not None and len(self.t[0]) >= 4:
+            self.sum9(out)
+
+    def tables_tensor(self):
+        return torch.from_numpy(np.stack([O.ints_to_mont(t) for t in self.t]).view(np.int64))
+
+    def finish(self, tables, transcript):
+        """the remaining tables on one rank: libzkmi's host degree-2 prover"""
+        return sharded.prove_sum2x2_host(transcript, tables.numpy().view(np.uint64))
+
+
+def _worker4(rank, world, port, log_n, gather_log, outdir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -173,15 +208,16 @@ def _worker4(rank, world, port, log_n, outdir):
         tabs = [O.gen_table(SEED + 10 + k, 0, n) for k in range(4)]
         tr = zk_amd.Transcript()
         tr.append(b"degree-2 sharded")
-        coeffs, ch = sharded.generate_round_polys_sum2x2_sharded(OracleShard4([t[rank::world] for t in tabs]), tr, world, dist)
+        coeffs, ch = sharded.generate_round_polys_sum2x2_sharded(OracleShard4([t[rank::world] for t in tabs]), tr, world, dist, None, gather_log)
         np.savez(os.path.join(outdir, f"q{rank}.npz"), coeffs=coeffs, ch=ch, digest=np.frombuffer(tr.peek_digest(), dtype=np.uint8))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,log_n", [(2, 6), (4, 5), (2, 2), (4, 3)])
-def test_sharded_degree2_matches_unsharded_oracle(tmp_path, world, log_n):
-    mp.spawn(_worker4, args=(world, _free_port(), log_n, str(tmp_path)), nprocs=world, join=True)
+@pytest.mark.parametrize("world,log_n,gather_log", [(2, 6, None), (4, 5, None), (2, 2, None), (4, 3, None),
+                                                    (2, 7, 2), (4, 7, 1), (2, 6, 3), (2, 4, 13), (4, 2, 1), (2, 8, 0)])
+def test_sharded_degree2_matches_unsharded_oracle(tmp_path, world, log_n, gather_log):
+    mp.spawn(_worker4, args=(world, _free_port(), log_n, gather_log, str(tmp_path)), nprocs=world, join=True)
     tabs = [O.gen_table(SEED + 10 + k, 0, 1 << log_n) for k in range(4)]
     otr = O.OTranscript()
     otr.append(b"degree-2 sharded")

@@ -677,7 +677,32 @@ static int prove_sum2x2_single(zk_ctx* c, const void* const tables[4], size_t le
     return ZK_OK;
 }
 
-// two rounds per device pass (kernels.hip, "degree-2 branch, TWO rounds per pass")
+// the host part of two rounds from the nine sums S[3Y + t] (kernels.hip, "degree-2 branch, TWO rounds per pass")
+static void host_round_pair_from_sum9(zk_transcript* tr, const Fq S[9], uint64_t* coeffs_out /* 2 x 3 */, uint64_t rs[8]) {
+    // round k binds b1: ev(X) = sum_{Y in {0,1}} [S0 + X (S1 - S0 - S2) + X^2 S2](Y)
+    Fq mid[3]; // S1 - S0 - S2 per Y
+    for (int Y = 0; Y < 3; ++Y) mid[Y] = zkh::sub(zkh::sub(S[3 * Y + 1], S[3 * Y]), S[3 * Y + 2]);
+    Fq ev[3];
+    ev[0] = zkh::add(S[0], S[3]);
+    ev[1] = zkh::add(S[1], S[4]);
+    {
+        Fq e2 = zkh::zero();
+        for (int Y = 0; Y < 2; ++Y) {
+            const Fq two_mid = zkh::add(mid[Y], mid[Y]), two_s2 = zkh::add(S[3 * Y + 2], S[3 * Y + 2]);
+            e2 = zkh::add(e2, zkh::add(zkh::add(S[3 * Y], two_mid), zkh::add(two_s2, two_s2)));
+        }
+        ev[2] = e2;
+    }
+    const Fq r = host_round_deg2(tr, ev, coeffs_out);
+    zkh::store(rs, r);
+    // round k+1 binds b2 with b1 = r: ev'(Y) = S0 + r (S1 - S0 - S2) + r^2 S2
+    const Fq r2 = zkh::mul(r, r);
+    for (int Y = 0; Y < 3; ++Y) ev[Y] = zkh::add(zkh::add(S[3 * Y], zkh::mul(r, mid[Y])), zkh::mul(r2, S[3 * Y + 2]));
+    const Fq s2 = host_round_deg2(tr, ev, coeffs_out + 12);
+    zkh::store(rs + 4, s2);
+}
+
+// two rounds per device pass
 static int prove_sum2x2_pairs(zk_ctx* c, const void* const tables[4], size_t len, zk_transcript* tr, uint64_t* coeffs_out,
                               uint64_t* challenges_out, uint64_t* final_out) {
     int rc = set_device(c);
@@ -696,28 +721,8 @@ static int prove_sum2x2_pairs(zk_ctx* c, const void* const tables[4], size_t len
         HIPCHK(c, hipStreamSynchronize(c->stream));
         Fq S[9];
         for (int i = 0; i < 9; ++i) S[i] = zkh::load(c->sums_host + 4 * i);
-        // round k binds b1: ev(X) = sum_{Y in {0,1}} [S0 + X (S1 - S0 - S2) + X^2 S2](Y)
-        Fq mid[3]; // S1 - S0 - S2 per Y
-        for (int Y = 0; Y < 3; ++Y) mid[Y] = zkh::sub(zkh::sub(S[3 * Y + 1], S[3 * Y]), S[3 * Y + 2]);
-        Fq ev[3];
-        ev[0] = zkh::add(S[0], S[3]);
-        ev[1] = zkh::add(S[1], S[4]);
-        {
-            Fq e2 = zkh::zero();
-            for (int Y = 0; Y < 2; ++Y) {
-                const Fq two_mid = zkh::add(mid[Y], mid[Y]), two_s2 = zkh::add(S[3 * Y + 2], S[3 * Y + 2]);
-                e2 = zkh::add(e2, zkh::add(zkh::add(S[3 * Y], two_mid), zkh::add(two_s2, two_s2)));
-            }
-            ev[2] = e2;
-        }
         uint64_t rs[8];
-        const Fq r = host_round_deg2(tr, ev, coeffs_out + 12 * k);
-        zkh::store(rs, r);
-        // round k+1 binds b2 with b1 = r: ev'(Y) = S0 + r (S1 - S0 - S2) + r^2 S2
-        const Fq r2 = zkh::mul(r, r);
-        for (int Y = 0; Y < 3; ++Y) ev[Y] = zkh::add(zkh::add(S[3 * Y], zkh::mul(r, mid[Y])), zkh::mul(r2, S[3 * Y + 2]));
-        const Fq s2 = host_round_deg2(tr, ev, coeffs_out + 12 * (k + 1));
-        zkh::store(rs + 4, s2);
+        host_round_pair_from_sum9(tr, S, coeffs_out + 12 * k, rs);
         if (challenges_out) std::memcpy(challenges_out + 4 * k, rs, 2 * kElem);
         k += 2;
         // bind both variables in one sweep, then the nine sums of the result unless the host takes over
@@ -860,6 +865,70 @@ int zk_shard4_fold(zk_shard4* s, const uint64_t r[4], void* out_dev) {
     for (int t = 0; t < 4; ++t) s->cur[t] = dst[t];
     s->len = outlen;
     ++s->pass;
+    return ZK_OK;
+}
+
+// The same branch two rounds per exchange: every rank's share of the nine sums (linear in the entries, so the
+// shares add), the host part of both rounds, one 4-to-1 fold.
+int zk_sumcheck_round_pair_from_sum9(zk_transcript* t, const uint64_t* sums, int world, uint64_t coeffs_out[24], uint64_t challenges_out[8]) {
+    if (!t || !sums || !coeffs_out || !challenges_out || world < 1) return ZK_E_ARG;
+    Fq S[9];
+    for (int i = 0; i < 9; ++i) S[i] = zkh::zero();
+    for (int q = 0; q < world; ++q)
+        for (int i = 0; i < 9; ++i) S[i] = zkh::add(S[i], zkh::load(sums + 4 * (9 * (size_t)q + i)));
+    host_round_pair_from_sum9(t, S, coeffs_out, challenges_out);
+    return ZK_OK;
+}
+
+int zk_shard4_sum9(zk_shard4* s, void* sums_dev_out) {
+    if (!s || !sums_dev_out || s->len < 4) return ZK_E_ARG;
+    zk_ctx* c = s->ctx;
+    int rc = set_device(c);
+    if (rc) return rc;
+    {
+        ProfScope ps(c, ZK_K_SUM9, (uint64_t)s->len * 32 * 4);
+        zkk::launch_sum9(s->cur, s->len / 4, c->partials, sums_dev_out, c->stream);
+    }
+    HIPCHK(c, hipGetLastError());
+    return ZK_OK;
+}
+
+// bind the two top variables of the four tables at r2[0], r2[1]; sums_dev_out (9 elements, may be NULL) receives
+// the nine sums of the result when it keeps at least 4 entries per table
+int zk_shard4_fold2(zk_shard4* s, const uint64_t r2[8], void* sums_dev_out) {
+    if (!s || !r2 || s->len < 4) return ZK_E_ARG;
+    zk_ctx* c = s->ctx;
+    int rc = set_device(c);
+    if (rc) return rc;
+    const size_t outlen = s->len / 4;
+    if ((rc = ensure_work(c, s->pass & 1, 4 * outlen * kElem))) return rc;
+    void* dst[4];
+    for (int t = 0; t < 4; ++t) dst[t] = (uint8_t*)c->work[s->pass & 1] + (size_t)t * outlen * kElem;
+    uint32_t w28[4 * 10];
+    eq_weights28(r2, 2, w28);
+    {
+        ProfScope ps(c, ZK_K_FOLD2X4_SUM9, (uint64_t)s->len * 32 * 4 + (uint64_t)outlen * 32 * 4);
+        zkk::launch_fold2_tables(s->cur, dst, outlen, w28, c->stream);
+    }
+    if (sums_dev_out && outlen >= 4) {
+        ProfScope ps(c, ZK_K_SUM9, (uint64_t)outlen * 32 * 4);
+        zkk::launch_sum9(dst, outlen / 4, c->partials, sums_dev_out, c->stream);
+    }
+    HIPCHK(c, hipGetLastError());
+    for (int t = 0; t < 4; ++t) s->cur[t] = dst[t];
+    s->len = outlen;
+    ++s->pass;
+    return ZK_OK;
+}
+
+// dst_dev (4 x len elements, table after table) = the four current local tables; asynchronous
+int zk_shard4_copy_tables(zk_shard4* s, void* dst_dev) {
+    if (!s || !dst_dev) return ZK_E_ARG;
+    zk_ctx* c = s->ctx;
+    int rc = set_device(c);
+    if (rc) return rc;
+    for (int t = 0; t < 4; ++t)
+        HIPCHK(c, hipMemcpyAsync((uint8_t*)dst_dev + (size_t)t * s->len * kElem, s->cur[t], s->len * kElem, hipMemcpyDeviceToDevice, c->stream));
     return ZK_OK;
 }
 

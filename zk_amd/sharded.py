@@ -1,18 +1,23 @@
-"""Single-MLE sumcheck prover over a table sharded across the GPUs of one node.
+"""Sumcheck provers over tables sharded across the GPUs of one node.
 
 One process per GPU.  Rank q of `world` (a power of two, g = log2 world) holds the entries whose
 global index is q mod world, stored at index >> g: the table is sharded on the g variables that are
 bound LAST, so for the first n-g rounds every fold pair (j, j + N/2) of evaluation_form.rs:61-79
-lives on one GPU and the folds are rank-local.  The only exchange is the per-pass all-gather of the
-2^m block sums of every rank (<= 512 B per rank; RCCL over xGMI through torch.distributed, backend
-"nccl"); every rank then runs the identical host part (Keccak transcript, round polynomials,
-challenges), so nothing is broadcast back.  When the local tables are used up, the remaining
-g-variable table (one entry per rank) is already on every host -- it is each rank's block sums
-folded at the last challenges -- and the last g rounds run on the host.
+lives on one GPU and the folds are rank-local.  The only exchange per pass is the all-gather of every
+rank's small sums (2^m block sums for the MLE branch, nine sums per two rounds for the degree-2 branch;
+RCCL over xGMI through torch.distributed, backend "nccl"); every rank then runs the identical host part
+(Keccak transcript, round polynomials, challenges), so nothing is broadcast back.
 
-The loop is written against a small "shard" interface (vars_left / new_sums / block_sums / fold) so
-the multi-rank logic can be exercised on CPU ranks (gloo) in tests with a stand-in shard; the product
-shard is DeviceShard = zk_shard_* of libzkmi.so.  There is no CPU compute path in this package.
+Small passes are bound by the latency of that exchange, not by their work: once a rank's table is down to
+2^gather_log entries (default 2^13 = 256 KiB) the ranks all-gather the TABLES (entry j of rank q is entry
+j*world + q of what remains) and every rank finishes the remaining rounds alone with the single-GPU prover
+on the running transcript -- replicated work, no further exchange.  With gather_log=None the loops stay
+sharded to the end: when the local tables are used up, the remaining g-variable table (one entry per rank)
+is already on every host and the last g rounds run there.
+
+The loops are written against a small "shard" interface so the multi-rank logic can be exercised on CPU
+ranks (gloo) in tests with a stand-in shard; the product shards are DeviceShard / DeviceShard4 = zk_shard_* /
+zk_shard4_* of libzkmi.so.  There is no CPU compute path in this package.
 """
 from __future__ import annotations
 
@@ -294,6 +299,35 @@ class DeviceShard4:
         r = np.ascontiguousarray(r, dtype=np.uint64)
         check(lib().zk_shard4_fold(self.h, _ptr(r), C.c_void_p(out.data_ptr())), self.ctx.h)
 
+    # two rounds per exchange
+    def new_buf9(self):
+        return self._torch.empty((9, 4), dtype=self._torch.int64, device=self._torch.device("cuda", self.ctx.device_id))
+
+    def sum9(self, out) -> None:
+        check(lib().zk_shard4_sum9(self.h, C.c_void_p(out.data_ptr())), self.ctx.h)
+
+    def fold2(self, r2: np.ndarray, out) -> None:
+        r2 = np.ascontiguousarray(r2, dtype=np.uint64)
+        check(lib().zk_shard4_fold2(self.h, _ptr(r2), C.c_void_p(out.data_ptr()) if out is not None else None), self.ctx.h)
+
+    def tables_tensor(self):
+        """The four current local tables as one (4, len, 4) int64 device tensor (a copy, on the context stream)."""
+        out = self._torch.empty((4, self.local_len(), 4), dtype=self._torch.int64,
+                                device=self._torch.device("cuda", self.ctx.device_id))
+        check(lib().zk_shard4_copy_tables(self.h, C.c_void_p(out.data_ptr())), self.ctx.h)
+        return out
+
+    def finish(self, tables, transcript: Transcript):
+        """All remaining rounds on this GPU alone: `tables` (4, L, 4) are the whole remaining tables."""
+        from .polynomials import ProductPolynomial, SumPolynomial
+        from .sumcheck import SumcheckProver
+
+        tables = tables.contiguous()
+        t = [MultiLinearPolynomial.wrap_device(tables[k].data_ptr(), tables.shape[1], ctx=self.ctx) for k in range(4)]
+        f = SumPolynomial([ProductPolynomial(t[:2]), ProductPolynomial(t[2:])])
+        proof, ch = SumcheckProver.generate_proof_for_partial_verify(np.zeros(4, dtype=np.uint64), f, transcript)
+        return proof.round_polys, ch
+
     def close(self):
         if getattr(self, "h", None):
             lib().zk_shard4_end(self.h)
@@ -326,19 +360,65 @@ def prove_sum2x2_host(transcript: Transcript, tables: np.ndarray):
     return coeffs[:n], ch[:n]
 
 
-def generate_round_polys_sum2x2_sharded(shard4, transcript: Transcript, world: int, dist=None, group=None):
+def round_pair_from_sum9(transcript: Transcript, sums: np.ndarray):
+    """sums (world, 9, 4) -> (coefficients (2,3,4), challenges (2,4)); zk_sumcheck_round_pair_from_sum9, host only."""
+    sums = np.ascontiguousarray(sums, dtype=np.uint64)
+    coeffs = np.empty((2, 3, 4), dtype=np.uint64)
+    r = np.empty((2, 4), dtype=np.uint64)
+    check(lib().zk_sumcheck_round_pair_from_sum9(transcript.h, _ptr(sums), sums.shape[0], _ptr(coeffs), _ptr(r)))
+    return coeffs, r
+
+
+def gather_tables4(local, world: int, dist=None, group=None):
+    """all-gather of the ranks' four local tables (4, L, 4) -> the remaining tables (4, world * L, 4), entry
+    j*world + q = rank q's entry j."""
+    import torch
+
+    if world == 1 or dist is None:
+        return local
+    if dist.get_backend(group) == "nccl":
+        out = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(out, local.contiguous(), group=group)
+    else:
+        host = local.cpu().contiguous()
+        parts = [torch.empty_like(host) for _ in range(world)]
+        dist.all_gather(parts, host, group=group)
+        out = torch.stack(parts).to(local.device)
+    return out.permute(1, 2, 0, 3).contiguous().reshape(4, -1, 4)
+
+
+def generate_round_polys_sum2x2_sharded(shard4, transcript: Transcript, world: int, dist=None, group=None,
+                                        gather_log: int | None = DEFAULT_GATHER_LOG):
     """generate_round_polys (sumcheck/src/prover.rs:45-155, SumPolynomial branch) for four tables sharded on
-    the variables bound last.  Every rank returns the same (round_polys (n,3,4), challenges (n,4))."""
+    the variables bound last.  Every rank returns the same (round_polys (n,3,4), challenges (n,4)).
+    gather_log (>= 1): two rounds per exchange (nine sums per rank) while a rank's tables have more than
+    2^gather_log entries, then the ranks all-gather their tables and every rank finishes alone (replicated).
+    None: one round per exchange (three evaluation shares), sharded to the end, host tail over the rank bits."""
     g = world.bit_length() - 1
     if world != 1 << g:
         raise ValueError("world size must be a power of two")
     ln = shard4.local_len()
     ell = ln.bit_length() - 1
-    if ell < 1:
-        raise ValueError("each rank needs at least 2 local entries per table")
     n = ell + g
     coeffs = np.empty((n, 3, 4), dtype=np.uint64)
     ch = np.empty((n, 4), dtype=np.uint64)
+    if gather_log is not None and hasattr(shard4, "finish"):
+        T = max(1, gather_log)
+        k = 0
+        if ell > T:
+            buf = shard4.new_buf9()
+            shard4.sum9(buf)
+            while ell > T:  # ell >= 2
+                sums = gather_sums(buf, world, dist, group)
+                coeffs[k:k + 2], ch[k:k + 2] = round_pair_from_sum9(transcript, sums)
+                ell -= 2
+                shard4.fold2(ch[k:k + 2], buf if ell > T else None)
+                k += 2
+        c, r = shard4.finish(gather_tables4(shard4.tables_tensor(), world, dist, group), transcript)
+        coeffs[k:], ch[k:] = c, r
+        return coeffs, ch
+    if ell < 1:
+        raise ValueError("each rank needs at least 2 local entries per table")
     buf = shard4.new_buf()
     shard4.eval(buf)
     for k in range(ell):
