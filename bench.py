@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--fold-batch", type=int, default=0, help="rounds bound per device pass (0 = library default)")
     ap.add_argument("--wide-batch", type=int, default=-1, help="rounds bound by a pass over a large table (5..8, 0 = off, -1 = library default 8)")
     ap.add_argument("--wide-min-log-out", type=int, default=16, help="wide passes are taken while the folded table keeps >= 2^k entries")
+    ap.add_argument("--wide-lds-below", type=int, default=19, help="wide passes with < 2^k outputs make their weights per workgroup in LDS")
     ap.add_argument("--fold-variant", type=int, default=0, help="0 eq-weight inner product, 1 tree, 2 tree+double buffer")
     ap.add_argument("--deg2-rounds", type=int, default=0, help="degree-2 prover: rounds per device pass (1 or 2; 0 = library default, 2)")
     ap.add_argument("--gather-log", type=int, default=13, help="multi-GPU: local tables of <= 2^k entries are all-gathered and finished on every rank (-1 = sharded to the end)")
@@ -146,7 +147,7 @@ def main():
         if args.fold_batch:
             ctx.set_fold_batch(args.fold_batch, args.fold_variant)
         if args.wide_batch >= 0:
-            ctx.set_wide_fold(args.wide_batch, args.wide_min_log_out)
+            ctx.set_wide_fold(args.wide_batch, args.wide_min_log_out, args.wide_lds_below)
         result = bench_single(args, ctx, zk_amd, np)
 
     torch.cuda.synchronize()
@@ -238,7 +239,7 @@ def bench_single(args, ctx, zk_amd, np):
     ms_per_step = dt * 1e3 / args.steps
 
     kernels = {}
-    for name in ("block_sums", "multifold", "eval3", "fold4_eval3", "sum9", "fold2x4_sum9"):
+    for name in ("block_sums", "multifold_wide", "multifold", "eval3", "fold4_eval3", "sum9", "fold2x4_sum9"):
         p = ctx.prof_read(name)
         if p["launches"]:
             kernels[name] = {
@@ -246,12 +247,14 @@ def bench_single(args, ctx, zk_amd, np):
                 "alg_bytes_per_launch": p["alg_bytes"] / p["launches"],
                 "achieved_GBs": p["alg_bytes"] / (p["ms"] * 1e-3) / 1e9 if p["ms"] > 0 else None,
             }
+    if kernel == "multifold" and "multifold_wide" in kernels:
+        kernel = "multifold_wide"  # the wide pass over the full table is where the fold time goes (k_multifold_wide)
     dom = kernels[kernel]
     roofline = {
         "bound": "hbm", "kernel": kernel, "achieved": dom["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": dom["achieved_GBs"] / HBM_PEAK_GBS, "traffic": pmc_traffic(kernel, args.log_n),
         "note": "achieved = algorithmic bytes of all launches of the kernel in the timed steps / their summed "
-                "HIP-event durations (multifold: 32 B per input entry read + 32 B per output entry written; "
+                "HIP-event durations (multifold / multifold_wide: 32 B per input entry read + 32 B per output entry written; "
                 "fold4_eval3: 48 B per input entry per table; fold2x4_sum9: 32 B per input + 32 B per output entry per table)",
     }
     # int32-ALU side: Montgomery multiplies per second from the in-register probe
@@ -288,7 +291,7 @@ def bench_sharded(args, zk_amd, np, dist, rank, local_rank, world):
     if args.fold_batch:
         ctx.set_fold_batch(args.fold_batch, args.fold_variant)
     if args.wide_batch >= 0:
-        ctx.set_wide_fold(args.wide_batch, args.wide_min_log_out)
+        ctx.set_wide_fold(args.wide_batch, args.wide_min_log_out, args.wide_lds_below)
     gather_log = args.gather_log if args.gather_log >= 0 else None
     fold_batch = None  # the library's schedule (zk_shard_next_batch): the same passes as the single-GPU prover
     base = zk_amd.Transcript()
@@ -303,7 +306,7 @@ def bench_sharded(args, zk_amd, np, dist, rank, local_rank, world):
             finally:
                 sh.close()
 
-        dom_kernel, names = "multifold", ("block_sums", "multifold")
+        dom_kernel, names = "multifold", ("block_sums", "multifold_wide", "multifold")
         what = f"single-MLE sumcheck, 2^{log_total} entries"
         exchange = f"all-gather of 2^m block sums per pass ({dist.get_backend()}), library pass schedule; tables of <= 2^{args.gather_log} entries per rank all-gathered and finished on every rank"
     else:
@@ -360,6 +363,8 @@ def bench_sharded(args, zk_amd, np, dist, rank, local_rank, world):
                 "alg_bytes_per_launch": p["alg_bytes"] / p["launches"],
                 "achieved_GBs": p["alg_bytes"] / (p["ms"] * 1e-3) / 1e9 if p["ms"] > 0 else None,
             }
+    if dom_kernel == "multifold" and "multifold_wide" in kernels:
+        dom_kernel = "multifold_wide"
     dom = kernels[dom_kernel]
     roofline = {
         "bound": "hbm", "kernel": dom_kernel, "achieved": dom["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",

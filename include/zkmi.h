@@ -265,12 +265,14 @@ int zk_ctx_set_fold_batch(zk_ctx *ctx, int rounds_per_pass, int variant);
 /* Passes over a LARGE table bind up to `rounds` variables at once (5..8, default 8; 0 = off): as many as leave
  * the folded table at least 2^min_log_out entries (default 16), when that is `rounds` itself or at least two more
  * than the default batch.  At 2^8 read streams per store stream the pass runs at the read-only HBM rate
- * (fold-pass ceiling).  Proof bytes do not depend on it. */
-int zk_ctx_set_wide_fold(zk_ctx *ctx, int rounds, int min_log_out);
+ * (fold-pass ceiling).  lds_weights_below_log (default 19; 0 = never, 64 = always): wide passes with
+ * fewer than 2^k outputs derive their weights per workgroup in LDS (one launch, latency matters), larger ones
+ * read them from a small device buffer as scalar loads (4 waves per SIMD).  Proof bytes do not depend on any of it. */
+int zk_ctx_set_wide_fold(zk_ctx *ctx, int rounds, int min_log_out, int lds_weights_below_log);
 /* Rounds bound per device pass by the degree-2 prover: 2 (default; nine sums serve two rounds) or 1 (one
  * evaluation triple per pass).  Proof bytes do not depend on it. */
 int zk_ctx_set_deg2_rounds_per_pass(zk_ctx *ctx, int rounds);
-enum { ZK_K_BLOCK_SUMS = 0, ZK_K_MULTIFOLD = 1, ZK_K_FOLD = 2, ZK_K_EVAL3 = 3, ZK_K_FOLD4_EVAL3 = 4, ZK_K_SUM9 = 5, ZK_K_FOLD2X4_SUM9 = 6,
+enum { ZK_K_BLOCK_SUMS = 0, ZK_K_MULTIFOLD = 1, ZK_K_FOLD = 2, ZK_K_EVAL3 = 3, ZK_K_FOLD4_EVAL3 = 4, ZK_K_SUM9 = 5, ZK_K_FOLD2X4_SUM9 = 6, ZK_K_MULTIFOLD_WIDE = 7,
        ZK_K_COUNT = 8 };
 /* per-kernel HIP-event timing of the launches made by the provers on this context */
 int zk_prof_enable(zk_ctx *ctx, int on);

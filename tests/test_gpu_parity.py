@@ -174,12 +174,12 @@ def test_sumcheck_every_fold_batch_setting_gives_the_same_proof(batch, db):
         c.set_fold_batch(9, 0)
 
 
-@pytest.mark.parametrize("wide,min_log_out", [(8, 2), (8, 5), (7, 3), (6, 0), (5, 4), (0, 17)])
-def test_sumcheck_wide_first_passes_give_the_same_proof(wide, min_log_out):
+@pytest.mark.parametrize("wide,min_log_out,lds_below", [(8, 2, 19), (8, 5, 0), (7, 3, 0), (6, 0, 64), (5, 4, 0), (0, 17, 19), (8, 3, 12), (6, 1, 0)])
+def test_sumcheck_wide_first_passes_give_the_same_proof(wide, min_log_out, lds_below):
     """The pass schedule (wide 2^m-stream passes while the table is large, the default batch after that) is not
     part of the protocol: the thresholds are lowered here so that small tables take one or more wide passes."""
     c = zk_amd.Context(0)
-    c.set_wide_fold(wide, min_log_out)
+    c.set_wide_fold(wide, min_log_out, lds_below)  # lds_below = 0: the scalar-weight kernel on every wide pass
     for log_n in (4, 9, 10, 11, 13, 16, 18):
         table = O.gen_table(SEED + 80 + log_n, 0, 1 << log_n)
         poly = MLE(table, ctx=c)
@@ -193,7 +193,7 @@ def test_sumcheck_wide_first_passes_give_the_same_proof(wide, min_log_out):
         assert np.array_equal(poly.evaluate(pts).get_evaluation_points(), O.mle_evaluate(table, pts)), (wide, min_log_out, log_n)
         part = pts[: log_n - 2] + [None, None]
         assert np.array_equal(poly.evaluate(part).get_evaluation_points(), O.mle_evaluate(table, part)), (wide, min_log_out, log_n)
-    for bad in ((4, 17), (9, 17), (8, -1)):
+    for bad in ((4, 17, 19), (9, 17, 19), (8, -1, 19), (8, 16, 65)):
         with pytest.raises(zk_amd.ZkError):
             c.set_wide_fold(*bad)
 

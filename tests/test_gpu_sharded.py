@@ -37,7 +37,7 @@ def _worker(rank, world, port, backend, log_n, fold_batch, generated, outdir, ga
     try:
         ctx = sharded.torch_stream_context(0)
         if fold_batch is None:  # the library's own schedule, with the wide passes switched on for tables this small
-            ctx.set_wide_fold(8, 2)
+            ctx.set_wide_fold(8, 2, 10)
         n = 1 << log_n
         if generated:  # made on the device, strided
             local = zk_amd.MultiLinearPolynomial.generate(SEED, n // world, first=rank, step=world, ctx=ctx)

@@ -89,6 +89,75 @@ __global__ void __launch_bounds__(256) k_mem(const fq* __restrict__ src, fq* __r
     }
 }
 
+// the wide pass (k_multifold_wide) with knobs: G elements per load buffer; ALU 0 = xor only, 1 = full inner product,
+// 2 = half the limb products (sensitivity to the arithmetic); weights from LDS as in the library kernel
+template <int G, int ALU, int WS = 0>
+__global__ void __launch_bounds__(256) k_wide_exp(const fq* __restrict__ src, fq* __restrict__ dst, size_t Lout, int m, const u32* __restrict__ wsrc) {
+    __shared__ u32 wl[256 * 10];
+    if (!WS) {
+        for (int t = threadIdx.x; t < (10 << m); t += 256) wl[t] = wsrc[t];
+        __syncthreads();
+    }
+    const int ng = (1 << m) / G;
+    const size_t stride = (size_t)gridDim.x * 256, gstep = (size_t)G * Lout;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    fq A[G], B[G];
+    if (i < Lout) lazy_load<G>(A, src, Lout, i, 0);
+    while (i < Lout) {
+        const size_t n = i + stride;
+        u64 acc[20];
+#pragma unroll
+        for (int k = 0; k < 20; ++k) acc[k] = 0;
+        const fq* __restrict__ p = src + i;
+        const u32* __restrict__ w = WS ? wsrc : wl;
+        for (int g = 0; g < ng; g += 2) {
+            lazy_load<G>(B, p + gstep, Lout, 0, 0);
+#pragma unroll
+            for (int b = 0; b < G; ++b) {
+                if (ALU == 1) fq28_mac(acc, A[b], w + b * 10);
+                else if (ALU == 2) { u32 l[10]; fq28_unpack(A[b], l);
+#pragma unroll
+                    for (int j = 0; j < 5; ++j) { const u32 wj = w[b * 10 + j];
+#pragma unroll
+                        for (int q = 0; q < 10; ++q) acc[q + j] += (u64)l[q] * wj; } }
+                else {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) acc[q] ^= A[b].v[q];
+                }
+            }
+            if (g + 2 < ng) lazy_load<G>(A, p + 2 * gstep, Lout, 0, 0);
+            else if (n < Lout) lazy_load<G>(A, src, Lout, n, 0);
+#pragma unroll
+            for (int b = 0; b < G; ++b) {
+                if (ALU == 1) fq28_mac(acc, B[b], w + (G + b) * 10);
+                else if (ALU == 2) { u32 l[10]; fq28_unpack(B[b], l);
+#pragma unroll
+                    for (int j = 0; j < 5; ++j) { const u32 wj = w[(G + b) * 10 + j];
+#pragma unroll
+                        for (int q = 0; q < 10; ++q) acc[q + j] += (u64)l[q] * wj; } }
+                else {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) acc[q] ^= B[b].v[q];
+                }
+            }
+            if (ALU) {
+#pragma unroll
+                for (int k = 0; k < 19; ++k) { acc[k + 1] += acc[k] >> 28; acc[k] &= FQ28_MASK; }
+            }
+            p += 2 * gstep;
+            w += 2 * G * 10;
+        }
+        fq o;
+        if (ALU) o = fq28_redc(acc);
+        else {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) o.v[q] = (u32)acc[q];
+        }
+        fq_store(dst + i, o);
+        i = n;
+    }
+}
+
 template <int M>
 __global__ void __launch_bounds__(256) k_alu(fq* __restrict__ io, W28<M> W, int outputs_per_thread) {
     const size_t tid = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -127,7 +196,7 @@ int main(int argc, char** argv) {
     fq *src, *dst, *part, *sums;
     CHK(hipMalloc(&src, n * 32));
     CHK(hipMalloc(&dst, n * 32)); // sized for the widest ablation (1 stream: as many outputs as inputs)
-    CHK(hipMalloc(&part, 2048 * 3 * 32));
+    CHK(hipMalloc(&part, 2048 * 3 * 32)); // >= 2 * kMaxBlocks partials of the wide pass
     CHK(hipMalloc(&sums, 256 * 32)); // up to 2^8 block sums
     launch_generate(src, 1, 0, 1, n, 0);
     CHK(hipDeviceSynchronize());
@@ -193,15 +262,41 @@ int main(int argc, char** argv) {
         float ms = timeit([&] { launch_multifold_lazy(4, group, src, dst, Lout, w28, 4, part, sums, 0); }, a, b);
         printf("real launch_multifold_lazy group %3d: %8.1f GB/s (%.3f ms)\n", group, bytes / ms / 1e6, ms);
     }
+    u32* wbuf; CHK(hipMalloc(&wbuf, kWideWeightWords * 4));
     for (int m : {5, 6, 7, 8}) {
         uint64_t r[4 * 8], two24[4] = {1u << 24, 0, 0, 0}; // any values below p: timing only
         for (int i = 0; i < 32; ++i) r[i] = 0x0123456789abcdefull >> (i % 4 == 3 ? 8 : 0);
         const size_t lo = n >> m;
         for (int log_ob : {4, 8}) {
-            float ms = timeit([&] { launch_multifold_wide(m, src, dst, lo, r, two24, log_ob, part, sums, 0); }, a, b);
+            float ms = timeit([&] { launch_multifold_wide(m, src, dst, lo, r, two24, wbuf, 19, log_ob, part, sums, 0); }, a, b);
             printf("real launch_multifold_wide m = %d (%3d streams), %3d output blocks: %8.1f GB/s (%.3f ms)\n", m, 1 << m, 1 << log_ob,
                    ((double)n * 32 + (double)lo * 32) / ms / 1e6, ms);
         }
+    }
+    {
+        u32* wdev; CHK(hipMalloc(&wdev, 2560 * 4));
+        std::vector<u32> wh(2560);
+        for (int i = 0; i < 2560; ++i) wh[i] = (0x9E3779B9u * (i + 1)) & 0x0fffffffu;
+        CHK(hipMemcpy(wdev, wh.data(), 2560 * 4, hipMemcpyHostToDevice));
+        const size_t lo = n >> 8;
+#define RUNW(Gv, ALUv, GRID, label) RUNWS(Gv, ALUv, 0, GRID, label)
+#define RUNWS(Gv, ALUv, WSv, GRID, label)                                                                                                  \
+    {                                                                                                                                      \
+        float ms = timeit([&] { hipLaunchKernelGGL((k_wide_exp<Gv, ALUv, WSv>), dim3(GRID), dim3(256), 0, 0, src, dst, lo, 8, wdev); }, a, b); \
+        printf("wide exp m = 8, G = %d, %-18s grid %5d: %8.1f GB/s (%.3f ms)\n", Gv, label, GRID, ((double)n * 32 + (double)lo * 32) / ms / 1e6, ms); \
+    }
+        RUNW(4, 0, 2048, "xor only");
+        RUNW(4, 2, 2048, "half the products");
+        RUNW(4, 1, 2048, "full");
+        RUNW(4, 1, 1024, "full");
+        RUNW(4, 1, 4096, "full");
+        RUNW(8, 0, 2048, "xor only");
+        RUNW(8, 1, 2048, "full");
+        RUNW(2, 1, 2048, "full");
+        RUNW(2, 1, 4096, "full");
+        RUNWS(2, 1, 1, 2048, "full, scalar w");
+        RUNWS(2, 1, 1, 4096, "full, scalar w");
+        RUNWS(4, 1, 1, 2048, "full, scalar w");
     }
     {
         float ms = timeit([&] { launch_block_sums(src, n, 8, part, sums, 0); }, a, b);

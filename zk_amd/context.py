@@ -5,7 +5,7 @@ import ctypes as C
 
 from ._lib import check, lib
 
-KERNELS = {"block_sums": 0, "multifold": 1, "fold": 2, "eval3": 3, "fold4_eval3": 4, "sum9": 5, "fold2x4_sum9": 6}
+KERNELS = {"block_sums": 0, "multifold": 1, "fold": 2, "eval3": 3, "fold4_eval3": 4, "sum9": 5, "fold2x4_sum9": 6, "multifold_wide": 7}
 
 
 class Context:
@@ -37,10 +37,11 @@ class Context:
         2 = tree + double buffering, 3..6 = load-pipelining variants of 0."""
         check(lib().zk_ctx_set_fold_batch(self.h, rounds_per_pass, variant))
 
-    def set_wide_fold(self, rounds: int = 8, min_log_out: int = 16):
-        """Passes over a large table bind `rounds` (5..8; 0 = off) variables while the folded table keeps at least
-        2^min_log_out entries.  Proof bytes do not depend on it."""
-        check(lib().zk_ctx_set_wide_fold(self.h, rounds, min_log_out))
+    def set_wide_fold(self, rounds: int = 8, min_log_out: int = 16, lds_weights_below_log: int = 19):
+        """Passes over a large table bind up to `rounds` (5..8; 0 = off) variables while the folded table keeps at least
+        2^min_log_out entries; wide passes with fewer than 2^lds_weights_below_log outputs make their weights per
+        workgroup in LDS, larger ones read them as scalar loads.  Proof bytes do not depend on it."""
+        check(lib().zk_ctx_set_wide_fold(self.h, rounds, min_log_out, lds_weights_below_log))
 
     def set_deg2_rounds_per_pass(self, rounds: int):
         """Degree-2 prover schedule: 2 rounds per device pass (default) or 1.  Proof bytes do not depend on it."""

@@ -27,9 +27,12 @@ int launch_multifold(int m, const void* src, void* dst, size_t Lout, const uint6
 // group = elements per register load buffer (2 or 4)
 int launch_multifold_lazy(int m, int group, const void* src, void* dst, size_t Lout, const uint32_t* w28, int log_ob, void* partials,
                           void* out, hipStream_t st);
-// the same pass for 3 <= m <= kMaxFoldBatch: weights derived on the device from the challenges r[0..m); two24 = 2^24 (Montgomery)
-int launch_multifold_wide(int m, const void* src, void* dst, size_t Lout, const uint64_t* r, const uint64_t two24[4], int log_ob,
-                          void* partials, void* out, hipStream_t st);
+// the same pass for 3 <= m <= kMaxFoldBatch: weights derived on the device from the challenges r[0..m); two24 = 2^24
+// (Montgomery).  Outputs below 2^lds_below_log entries: per workgroup in LDS (one launch); larger ones: by a one-workgroup
+// kernel into wbuf (device, kWideWeightWords u32), read as scalar loads.  partials must hold 2 * kMaxBlocks elements
+static constexpr int kWideWeightWords = (1 << kMaxFoldBatch) * 10;
+int launch_multifold_wide(int m, const void* src, void* dst, size_t Lout, const uint64_t* r, const uint64_t two24[4], void* wbuf,
+                          int lds_below_log, int log_ob, void* partials, void* out, hipStream_t st);
 void launch_fold_var(const void* src, void* dst, size_t n_out, int log_s, const uint64_t r[4], hipStream_t st);
 void launch_reduce_partials(const void* partials, int nblocks, int ns, void* out, hipStream_t st);
 int launch_sum_all(const void* T, size_t n, void* partials, hipStream_t st);

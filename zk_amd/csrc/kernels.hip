@@ -9,6 +9,7 @@
 // All kernels are HBM-streaming integer kernels: no LDS tiling (no reuse), no MFMA.  Grids are
 // capped at kMaxBlocks x 256 threads and grid-stride, block -> per-block partial sums, one
 // small second-stage kernel folds the partials (fixed order: results are bit-reproducible).
+#include <cstdlib>
 #include "fq_dev.hpp"
 #include "kernels.h"
 
@@ -272,23 +273,112 @@ __global__ void __launch_bounds__(kThreads) k_multifold_roll(const fq* __restric
 // pass cost the same ~20 % of the HBM rate whether they are 1/2 or 1/16 of the traffic (tools/mfbench,
 // profiles/r01_mfbench_fold_pass_ablation.txt); only at 1/256 does the pass run at the read-only rate, so the
 // first pass over a large table binds eight variables.  2^m x 10 weight limbs no longer fit in kernel
-// arguments: every workgroup derives them from the m challenges into LDS (m + 1 dependent products), the
-// group loop stays rolled (its body is 8 inner products) and reads the weights as LDS broadcasts, and the
-// columns are carried once per loop trip so that they stay below 2^64 however many products are summed.
+// arguments: k_eq_weights28 (one workgroup, m + 1 dependent products) derives them from the m challenges into a
+// small device buffer and the fold reads them with wave-uniform addresses, i.e. as scalar loads into SGPRs --
+// no VGPRs and no LDS for the weights.  The group loop stays rolled (its body is 4 inner products), two
+// elements per load buffer keep the kernel at 4 waves per SIMD (the arithmetic, 1.0 ms of a 1.5 ms pass, only
+// hides under the loads with enough waves: 2 waves/SIMD measured 5.2 TB/s, 4 waves 5.6), and the columns are
+// carried once per loop trip so that they stay below 2^64 however many products are summed.
 struct ChalWide {
     fq r[kMaxFoldBatch];
     fq two24; // 2^24 in Montgomery form: eq * 2^256 -> eq * 2^280 (fq28_redc divides by 2^280)
 };
 
-__global__ void __launch_bounds__(kThreads) k_multifold_wide(const fq* __restrict__ src, fq* __restrict__ dst, size_t Lout, ChalWide ch, int m,
+// wout[b * 10 + j] = limb j of eq(r, b) * 2^280 mod p, b < 2^m; challenge l sits on bit m-1-l of b.  One workgroup.
+__global__ void __launch_bounds__(kThreads) k_eq_weights28(ChalWide ch, int m, u32* __restrict__ wout) {
+    __shared__ fq eq[1 << kMaxFoldBatch];
+    if (threadIdx.x == 0) {
+        eq[0] = ch.two24; // the tree is linear in its root: every weight comes out multiplied by 2^24
+    }
+    __syncthreads();
+    // level l appends variable l as the new least significant bit
+#pragma unroll
+    for (int l = 0; l < kMaxFoldBatch; ++l) {
+        if (l < m) {
+            const bool act = (int)threadIdx.x < (1 << l);
+            fq v, hi;
+            if (act) {
+                v = eq[threadIdx.x];
+                hi = fq_mul(v, ch.r[l]);
+            }
+            __syncthreads();
+            if (act) {
+                eq[2 * threadIdx.x + 1] = hi;
+                eq[2 * threadIdx.x] = fq_sub(v, hi);
+            }
+            __syncthreads();
+        }
+    }
+    if ((int)threadIdx.x < (1 << m)) {
+        u32 l28[10];
+        fq28_unpack(eq[threadIdx.x], l28);
+#pragma unroll
+        for (int j = 0; j < 10; ++j) wout[threadIdx.x * 10 + j] = l28[j];
+    }
+}
+
+template <bool BIG> // BIG: the output is beyond the caches: streaming stores
+__global__ void __launch_bounds__(kThreads) k_multifold_wide(const fq* __restrict__ src, fq* __restrict__ dst, size_t Lout,
+                                                              const u32* __restrict__ wts, int m, int log_ob, fq* __restrict__ partials) {
+    constexpr int G = 2;
+    const int ng = (1 << m) / G; // m >= 3: ng is even
+    const unsigned gpb = gridDim.x >> log_ob;
+    const unsigned c = blockIdx.x / gpb, wi = blockIdx.x % gpb;
+    const size_t Lb = Lout >> log_ob;
+    const size_t j0 = (size_t)c * Lb;
+    const unsigned stride = gpb * kThreads; // in-block indices fit 32 bits (the launcher checks): one register each
+    const size_t gstep = (size_t)G * Lout;
+    // the running sum of this lane's outputs lives in LDS: touched once per output (2^m elements apart), and the
+    // 8 registers it would hold are the difference between 3 and 4 waves per SIMD
+    __shared__ fq run[kThreads];
+    run[threadIdx.x] = fq_zero();
+    unsigned i = wi * kThreads + threadIdx.x;
+    fq A[G], B[G];
+    if (i < Lb) lazy_load<G>(A, src, Lout, j0 + i, 0);
+    while (i < Lb) {
+        const unsigned n = i + stride;
+        u64 acc[20];
+#pragma unroll
+        for (int k = 0; k < 20; ++k) acc[k] = 0;
+        const fq* __restrict__ p = src + j0 + i;
+        const u32* __restrict__ w = wts; // wave-uniform: scalar loads
+        for (int g = 0; g < ng; g += 2) {
+            lazy_load<G>(B, p + gstep, Lout, 0, 0);
+#pragma unroll
+            for (int b = 0; b < G; ++b) fq28_mac(acc, A[b], w + b * 10);
+            if (g + 2 < ng) lazy_load<G>(A, p + 2 * gstep, Lout, 0, 0);
+            else if (n < Lb) lazy_load<G>(A, src, Lout, j0 + n, 0);
+#pragma unroll
+            for (int b = 0; b < G; ++b) fq28_mac(acc, B[b], w + (G + b) * 10);
+            // carry: every column back below 2^28 (the top one keeps the overflow, which is tiny: the sum is < 2^8 p^2)
+#pragma unroll
+            for (int k = 0; k < 19; ++k) {
+                acc[k + 1] += acc[k] >> 28;
+                acc[k] &= FQ28_MASK;
+            }
+            p += 2 * gstep;
+            w += 2 * G * 10;
+        }
+        fq o = fq28_redc(acc);
+        if (BIG) fq_store_stream(dst + j0 + i, o); else fq_store(dst + j0 + i, o);
+        run[threadIdx.x] = fq_add(run[threadIdx.x], o);
+        i = n;
+    }
+    fq acc1[1] = {run[threadIdx.x]};
+    block_sum_store<1>(acc1, partials);
+}
+
+// The same pass for SMALL outputs (below 2^19 entries: a few waves per CU, time set by each lane's serial chain and by
+// launch latency, tools/wide_g_sweep.sh): every workgroup derives the weights itself into LDS -- no separate
+// k_eq_weights28 launch on the critical path -- and reads them as LDS broadcasts; 4 elements per load buffer.
+__global__ void __launch_bounds__(kThreads) k_multifold_wide_lds(const fq* __restrict__ src, fq* __restrict__ dst, size_t Lout, ChalWide ch, int m,
                                                               int log_ob, fq* __restrict__ partials) {
     constexpr int G = 4;
     __shared__ fq eq[1 << kMaxFoldBatch];
     __shared__ u32 wl[(1 << kMaxFoldBatch) * 10];
     const int nb = 1 << m, ng = nb / G; // m >= 3: ng is even
     if (threadIdx.x == 0) {
-        const fq one = {FQ_R_LIMBS};
-        eq[0] = one;
+        eq[0] = ch.two24; // the tree is linear in its root: every weight comes out multiplied by 2^24
     }
     __syncthreads();
     // eq(r, b), challenge l on bit m-1-l of b: level l appends variable l as the new least significant bit
@@ -311,7 +401,7 @@ __global__ void __launch_bounds__(kThreads) k_multifold_wide(const fq* __restric
     }
     if ((int)threadIdx.x < nb) {
         u32 l28[10];
-        fq28_unpack(fq_mul(eq[threadIdx.x], ch.two24), l28);
+        fq28_unpack(eq[threadIdx.x], l28);
 #pragma unroll
         for (int j = 0; j < 10; ++j) wl[threadIdx.x * 10 + j] = l28[j];
     }
@@ -720,14 +810,34 @@ int launch_multifold_lazy(int m, int group, const void* src, void* dst, size_t L
     hipLaunchKernelGGL(k_reduce_groups, dim3(1 << log_ob), dim3(kThreads), 0, st, (const fq*)partials, g >> log_ob, (fq*)out);
     return g;
 }
-int launch_multifold_wide(int m, const void* src, void* dst, size_t Lout, const uint64_t* r, const uint64_t two24[4], int log_ob,
-                          void* partials, void* out, hipStream_t st) {
-    if (m < 3 || m > kMaxFoldBatch) return -1;
+// grid for the wide pass: up to 2 * kMaxBlocks workgroups (16 per CU: the kernel runs 4 waves per SIMD)
+static inline int grid_blocks_wide(size_t Lb, int log_ob) {
+    size_t per = (Lb + kThreads - 1) / kThreads;
+    size_t cap = (size_t)(2 * kMaxBlocks) >> log_ob;
+    if (per > cap) per = cap;
+    if (per < 1) per = 1;
+    return (int)(per << log_ob);
+}
+int launch_multifold_wide(int m, const void* src, void* dst, size_t Lout, const uint64_t* r, const uint64_t two24[4], void* wbuf,
+                          int lds_below_log, int log_ob, void* partials, void* out, hipStream_t st) {
+    if (m < 3 || m > kMaxFoldBatch || (Lout >> log_ob) >= ((size_t)1 << 31)) return -1;
     ChalWide ch;
     for (int l = 0; l < kMaxFoldBatch; ++l) ch.r[l] = l < m ? to_fq(r + 4 * l) : fq{};
     ch.two24 = to_fq(two24);
-    int g = grid_blocks(Lout >> log_ob, log_ob);
-    hipLaunchKernelGGL(k_multifold_wide, dim3(g), dim3(kThreads), 0, st, (const fq*)src, (fq*)dst, Lout, ch, m, log_ob, (fq*)partials);
+    if (lds_below_log > 0 && (lds_below_log >= 63 || Lout < ((size_t)1 << lds_below_log))) { // small output: weights per workgroup in LDS
+        int g = grid_blocks(Lout >> log_ob, log_ob);
+        hipLaunchKernelGGL(k_multifold_wide_lds, dim3(g), dim3(kThreads), 0, st, (const fq*)src, (fq*)dst, Lout, ch, m, log_ob, (fq*)partials);
+        hipLaunchKernelGGL(k_reduce_groups, dim3(1 << log_ob), dim3(kThreads), 0, st, (const fq*)partials, g >> log_ob, (fq*)out);
+        return g;
+    }
+    hipLaunchKernelGGL(k_eq_weights28, dim3(1), dim3(kThreads), 0, st, ch, m, (u32*)wbuf);
+    int g = grid_blocks_wide(Lout >> log_ob, log_ob);
+    if (Lout >= ((size_t)1 << 22))
+        hipLaunchKernelGGL(k_multifold_wide<true>, dim3(g), dim3(kThreads), 0, st, (const fq*)src, (fq*)dst, Lout, (const u32*)wbuf, m, log_ob,
+                           (fq*)partials);
+    else
+        hipLaunchKernelGGL(k_multifold_wide<false>, dim3(g), dim3(kThreads), 0, st, (const fq*)src, (fq*)dst, Lout, (const u32*)wbuf, m, log_ob,
+                           (fq*)partials);
     hipLaunchKernelGGL(k_reduce_groups, dim3(1 << log_ob), dim3(kThreads), 0, st, (const fq*)partials, g >> log_ob, (fq*)out);
     return g;
 }

@@ -51,6 +51,7 @@ static int ctx_create(int device_id, bool own_stream, hipStream_t stream, zk_ctx
         (own_stream && fail(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking), "hipStreamCreate")) ||
         fail(hipMalloc(&c->partials, (size_t)std::max(zkk::kMaxBlocks * 3, zkk::kMaxBlocks9 * 18) * kElem), "hipMalloc partials") ||
         fail(hipMalloc(&c->sums_dev, kSums * kElem), "hipMalloc sums") ||
+        fail(hipMalloc(&c->wide_w, zkk::kWideWeightWords * sizeof(uint32_t)), "hipMalloc wide weights") ||
         fail(hipHostMalloc((void**)&c->sums_host, kHostStage * kElem, hipHostMallocMapped), "hipHostMalloc sums") ||
         fail(hipHostGetDevicePointer(&c->sums_host_dev, c->sums_host, 0), "hipHostGetDevicePointer")) {
         zk_ctx_destroy(c);
@@ -72,6 +73,7 @@ void zk_ctx_destroy(zk_ctx* c) {
     for (auto& p : c->prof_free) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     if (c->partials) (void)hipFree(c->partials);
     if (c->sums_dev) (void)hipFree(c->sums_dev);
+    if (c->wide_w) (void)hipFree(c->wide_w);
     if (c->sums_host) (void)hipHostFree(c->sums_host);
     if (c->work[0]) (void)hipFree(c->work[0]);
     if (c->work[1]) (void)hipFree(c->work[1]);
@@ -479,11 +481,11 @@ int zk_shard_fold(zk_shard* s, int m, const uint64_t* r_mont, int m_next, void* 
     void* dst = c->work[s->pass & 1];
     void* sums = m_next ? sums_dev_out : c->sums_dev;
     {
-        ProfScope ps(c, ZK_K_MULTIFOLD, (uint64_t)(lout << m) * 32 + (uint64_t)lout * 32);
+        ProfScope ps(c, m > zkk::kMaxLazyBatch ? ZK_K_MULTIFOLD_WIDE : ZK_K_MULTIFOLD, (uint64_t)(lout << m) * 32 + (uint64_t)lout * 32);
         if (m > zkk::kMaxLazyBatch) {
             uint64_t two24[4];
             zkh::store(two24, zkh::from_u64((uint64_t)1 << 24));
-            zkk::launch_multifold_wide(m, s->cur, dst, lout, r_mont, two24, m_next, c->partials, sums, c->stream);
+            zkk::launch_multifold_wide(m, s->cur, dst, lout, r_mont, two24, c->wide_w, c->wide_lds_below_log, m_next, c->partials, sums, c->stream);
         } else if (c->lazy && m >= 2) {
             uint32_t w28[(1 << zkk::kMaxLazyBatch) * 10];
             eq_weights28(r_mont, (unsigned)m, w28);
@@ -994,10 +996,13 @@ int zk_ctx_set_fold_batch(zk_ctx* c, int rounds_per_pass, int variant) {
     c->double_buffer = variant == 2;
     return ZK_OK;
 }
-int zk_ctx_set_wide_fold(zk_ctx* c, int rounds, int min_log_out) {
-    if (!c || (rounds != 0 && (rounds <= zkk::kMaxLazyBatch || rounds > zkk::kMaxFoldBatch)) || min_log_out < 0 || min_log_out > 40) return ZK_E_ARG;
+int zk_ctx_set_wide_fold(zk_ctx* c, int rounds, int min_log_out, int lds_weights_below_log) {
+    if (!c || (rounds != 0 && (rounds <= zkk::kMaxLazyBatch || rounds > zkk::kMaxFoldBatch)) || min_log_out < 0 || min_log_out > 40 ||
+        lds_weights_below_log < 0 || lds_weights_below_log > 64)
+        return ZK_E_ARG;
     c->wide_batch = rounds;
     c->wide_min_log_out = min_log_out;
+    c->wide_lds_below_log = lds_weights_below_log;
     return ZK_OK;
 }
 int zk_ctx_set_deg2_rounds_per_pass(zk_ctx* c, int rounds) {

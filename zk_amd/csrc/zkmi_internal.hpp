@@ -60,10 +60,12 @@ struct zk_ctx {
     bool own_stream = true;     // false: the caller's stream (zk_ctx_create_on_stream)
     void* partials = nullptr;   // kMaxBlocks * 3 elements
     void* sums_dev = nullptr;   // kSums elements
+    void* wide_w = nullptr;     // kWideWeightWords u32: eq weights of a wide fold pass (k_eq_weights28 -> k_multifold_wide)
     uint64_t* sums_host = nullptr; // pinned + device-mapped, kHostStage elements: kernels write small results here directly
     void* sums_host_dev = nullptr; // the device address of sums_host
     int fold_batch = 4;          // rounds bound per device pass (1..kMaxFoldBatch)
     int wide_batch = 8;          // rounds bound by a pass over a LARGE table (0: never; kernels.hip, k_multifold_wide) ...
+    int wide_lds_below_log = 19; // wide passes with fewer than 2^k outputs derive their weights per workgroup in LDS (one launch)
     int wide_min_log_out = 16;   // ... taken while its output keeps at least 2^wide_min_log_out entries
     bool double_buffer = false;  // register double-buffering in k_multifold (tree variant)
     bool lazy = true;            // inner-product form with one reduction per output (k_multifold_lazy)
