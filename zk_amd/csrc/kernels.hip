@@ -350,11 +350,14 @@ __global__ void __launch_bounds__(kThreads) k_multifold_wide(const fq* __restric
             else if (n < Lb) lazy_load<G>(A, src, Lout, j0 + n, 0);
 #pragma unroll
             for (int b = 0; b < G; ++b) fq28_mac(acc, B[b], w + (G + b) * 10);
-            // carry: every column back below 2^28 (the top one keeps the overflow, which is tiny: the sum is < 2^8 p^2)
+            // carry after every 16 products (the bound fq28_redc is written for): every column back below 2^28; the top one
+            // keeps the overflow, which is tiny -- the whole sum is < 2^8 p^2.  Uniform branch.
+            if ((g & 6) == 6) {
 #pragma unroll
-            for (int k = 0; k < 19; ++k) {
-                acc[k + 1] += acc[k] >> 28;
-                acc[k] &= FQ28_MASK;
+                for (int k = 0; k < 19; ++k) {
+                    acc[k + 1] += acc[k] >> 28;
+                    acc[k] &= FQ28_MASK;
+                }
             }
             p += 2 * gstep;
             w += 2 * G * 10;
@@ -433,11 +436,13 @@ __global__ void __launch_bounds__(kThreads) k_multifold_wide_lds(const fq* __res
             else if (n < Lb) lazy_load<G>(A, src, Lout, j0 + n, 0);
 #pragma unroll
             for (int b = 0; b < G; ++b) fq28_mac(acc, B[b], w + (G + b) * 10);
-            // carry: every column back below 2^28 (the top one keeps the overflow, which is tiny: the sum is < 2^8 p^2)
+            // carry after every 16 products (G = 4: every second trip), as above
+            if (g & 2) {
 #pragma unroll
-            for (int k = 0; k < 19; ++k) {
-                acc[k + 1] += acc[k] >> 28;
-                acc[k] &= FQ28_MASK;
+                for (int k = 0; k < 19; ++k) {
+                    acc[k + 1] += acc[k] >> 28;
+                    acc[k] &= FQ28_MASK;
+                }
             }
             p += 2 * gstep;
             w += 2 * G * 10;
