@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--fold-variant", type=int, default=0, help="0 eq-weight inner product, 1 tree, 2 tree+double buffer")
     ap.add_argument("--deg2-rounds", type=int, default=0, help="degree-2 prover: rounds per device pass (1 or 2; 0 = library default, 2)")
     ap.add_argument("--gather-log", type=int, default=13, help="multi-GPU: local tables of <= 2^k entries are all-gathered and finished on every rank (-1 = sharded to the end)")
+    ap.add_argument("--deg2-lazy-from", type=int, default=None, help="degree-2 prover: unreduced nine-sum accumulation from 2^k quarter-entries (negative = never)")
     ap.add_argument("--weak", action="store_true", help="multi-GPU: 2^log_n entries PER GPU instead of in total")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for the multi-GPU exchange")
     ap.add_argument("--shared-device", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
@@ -219,6 +220,8 @@ def bench_single(args, ctx, zk_amd, np):
 
         if args.deg2_rounds:
             ctx.set_deg2_rounds_per_pass(args.deg2_rounds)
+        if args.deg2_lazy_from is not None:
+            ctx.set_deg2_lazy_sums(args.deg2_lazy_from)
         kernel = "fold4_eval3" if args.deg2_rounds == 1 else "fold2x4_sum9"
         workload = f"degree-2 sumcheck Sum[Prod[f,g],Prod[h,k]], 4 x 2^{args.log_n} entries, 1 GPU"
 

@@ -287,12 +287,14 @@ def test_sum2x2_shape_errors(ctx):
     assert ei.value.status == 5
 
 
-@pytest.mark.parametrize("rounds_per_pass", [1, 2])
-def test_sum2x2_both_schedules_give_the_oracle_proof(rounds_per_pass):
-    """Two rounds per device pass (nine sums) or one (three evaluations): an execution schedule, same proof bytes."""
+@pytest.mark.parametrize("rounds_per_pass,lazy_from", [(1, 20), (2, 20), (2, 0), (2, 5), (2, -1)])
+def test_sum2x2_both_schedules_give_the_oracle_proof(rounds_per_pass, lazy_from):
+    """Two rounds per device pass (nine sums) or one (three evaluations), nine sums by per-product reduction or by
+    unreduced accumulation (lazy_from = 0: every sweep): execution schedules, same proof bytes."""
     c = zk_amd.Context(0)
     c.set_deg2_rounds_per_pass(rounds_per_pass)
-    for log_n in (2, 3, 6, 7, 8, 9, 11, 12, 14):
+    c.set_deg2_lazy_sums(lazy_from)
+    for log_n in (2, 3, 6, 7, 8, 9, 11, 12, 14, 17):
         n = 1 << log_n
         tabs = [O.gen_table(SEED + 90 + k, 0, n) for k in range(4)]
         m = [MLE(t, ctx=c) for t in tabs]

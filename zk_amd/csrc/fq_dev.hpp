@@ -107,6 +107,15 @@ __device__ __forceinline__ fq fq_sub_lazy(const fq& a, const fq& b) {
     return o;
 }
 
+// a + b as a plain 256-bit integer, no reduction (callers keep the sum below 2^256: up to four elements < p)
+__device__ __forceinline__ fq fq_add_plain(const fq& a, const fq& b) {
+    fq s;
+    u32 c = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s.v[j] = __builtin_addc(a.v[j], b.v[j], c, &c);
+    return s;
+}
+
 // 2a mod p
 __device__ __forceinline__ fq fq_dbl(const fq& a) { return fq_add(a, a); }
 
@@ -192,6 +201,22 @@ __device__ __forceinline__ void fq28_mac_limbs(u64 (&acc)[20], const u32 (&l)[10
         const u32 wj = w[j];
 #pragma unroll
         for (int i = 0; i < 10; ++i) acc[i + j] += (u64)l[i] * wj;
+    }
+}
+
+// acc += a * b, both operands already unpacked (variable x variable: the degree-2 sums)
+__device__ __forceinline__ void fq28_mac_vv(u64 (&acc)[20], const u32 (&a)[10], const u32 (&b)[10]) {
+#pragma unroll
+    for (int j = 0; j < 10; ++j)
+#pragma unroll
+        for (int i = 0; i < 10; ++i) acc[i + j] += (u64)a[i] * b[j];
+}
+// every column back below 2^28 (the top one keeps the overflow): call at least every 16 accumulated products
+__device__ __forceinline__ void fq28_carry(u64 (&acc)[20]) {
+#pragma unroll
+    for (int k = 0; k < 19; ++k) {
+        acc[k + 1] += acc[k] >> 28;
+        acc[k] &= FQ28_MASK;
     }
 }
 

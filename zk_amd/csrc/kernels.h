@@ -40,9 +40,11 @@ int launch_eval3(const void* const t[4], size_t half, void* partials, hipStream_
 int launch_fold4_eval3(const void* const s[4], void* const d[4], size_t q, const uint64_t r[4], void* partials, hipStream_t st);
 void launch_fold4(const void* const s[4], void* const d[4], size_t half, const uint64_t r[4], hipStream_t st);
 // degree-2 branch, two rounds per pass (kernels.hip): out[3Y + t] (9 elements) = the nine sums of four tables of 4q
-// entries; partials must hold 18 * kMaxBlocks9 elements
+// entries; partials must hold 18 * kMaxBlocks9 + 16 elements
 static constexpr int kMaxBlocks9 = 1024;
-void launch_sum9(const void* const t[4], size_t q, void* partials, void* out, hipStream_t st);
+// fix24 = 2^24 (Montgomery); tables of at least 2^lazy_from_log quarter-entries take the unreduced-accumulation kernel
+// (lazy_from_log < 0: never)
+void launch_sum9(const void* const t[4], size_t q, const uint64_t fix24[4], int lazy_from_log, void* partials, void* out, hipStream_t st);
 // bind the two top variables of four tables of 4*outlen entries (w28: the 4 eq weights as for launch_multifold_lazy)
 // into d[] (outlen entries each)
 void launch_fold2_tables(const void* const s[4], void* const d[4], size_t outlen, const uint32_t* w28, hipStream_t st);

@@ -38,6 +38,7 @@ static int ctx_create(int device_id, bool own_stream, hipStream_t stream, zk_ctx
     zk_ctx* c = new (std::nothrow) zk_ctx();
     if (!c) return ZK_E_ALLOC;
     c->device = device_id;
+    zkh::store(c->two24, zkh::from_u64((uint64_t)1 << 24));
     c->own_stream = own_stream;
     c->stream = stream;
     int rc = ZK_OK;
@@ -49,7 +50,7 @@ static int ctx_create(int device_id, bool own_stream, hipStream_t stream, zk_ctx
     };
     if (fail(hipSetDevice(device_id), "hipSetDevice") ||
         (own_stream && fail(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking), "hipStreamCreate")) ||
-        fail(hipMalloc(&c->partials, (size_t)std::max(zkk::kMaxBlocks * 3, zkk::kMaxBlocks9 * 18) * kElem), "hipMalloc partials") ||
+        fail(hipMalloc(&c->partials, (size_t)(std::max(zkk::kMaxBlocks * 3, zkk::kMaxBlocks9 * 18) + 16) * kElem), "hipMalloc partials") ||
         fail(hipMalloc(&c->sums_dev, kSums * kElem), "hipMalloc sums") ||
         fail(hipMalloc(&c->wide_w, zkk::kWideWeightWords * sizeof(uint32_t)), "hipMalloc wide weights") ||
         fail(hipHostMalloc((void**)&c->sums_host, kHostStage * kElem, hipHostMallocMapped), "hipHostMalloc sums") ||
@@ -483,9 +484,7 @@ int zk_shard_fold(zk_shard* s, int m, const uint64_t* r_mont, int m_next, void* 
     {
         ProfScope ps(c, m > zkk::kMaxLazyBatch ? ZK_K_MULTIFOLD_WIDE : ZK_K_MULTIFOLD, (uint64_t)(lout << m) * 32 + (uint64_t)lout * 32);
         if (m > zkk::kMaxLazyBatch) {
-            uint64_t two24[4];
-            zkh::store(two24, zkh::from_u64((uint64_t)1 << 24));
-            zkk::launch_multifold_wide(m, s->cur, dst, lout, r_mont, two24, c->wide_w, c->wide_lds_below_log, m_next, c->partials, sums, c->stream);
+            zkk::launch_multifold_wide(m, s->cur, dst, lout, r_mont, c->two24, c->wide_w, c->wide_lds_below_log, m_next, c->partials, sums, c->stream);
         } else if (c->lazy && m >= 2) {
             uint32_t w28[(1 << zkk::kMaxLazyBatch) * 10];
             eq_weights28(r_mont, (unsigned)m, w28);
@@ -716,7 +715,7 @@ static int prove_sum2x2_pairs(zk_ctx* c, const void* const tables[4], size_t len
     int pass = 0;
     if (curlen > kHostTail) {
         ProfScope ps(c, ZK_K_SUM9, (uint64_t)len * 32 * 4);
-        zkk::launch_sum9(cur, curlen / 4, c->partials, c->sums_host_dev, c->stream); // nine sums straight into pinned host memory
+        zkk::launch_sum9(cur, curlen / 4, c->two24, c->deg2_lazy_from_log, c->partials, c->sums_host_dev, c->stream); // nine sums straight into pinned host memory
     }
     while (curlen > kHostTail) {
         HIPCHK(c, hipGetLastError());
@@ -740,7 +739,7 @@ static int prove_sum2x2_pairs(zk_ctx* c, const void* const tables[4], size_t len
         }
         if (outlen > kHostTail) {
             ProfScope ps(c, ZK_K_SUM9, (uint64_t)outlen * 32 * 4);
-            zkk::launch_sum9(dst, outlen / 4, c->partials, c->sums_host_dev, c->stream);
+            zkk::launch_sum9(dst, outlen / 4, c->two24, c->deg2_lazy_from_log, c->partials, c->sums_host_dev, c->stream);
         }
         for (int t = 0; t < 4; ++t) cur[t] = dst[t];
         curlen = outlen;
@@ -889,7 +888,7 @@ int zk_shard4_sum9(zk_shard4* s, void* sums_dev_out) {
     if (rc) return rc;
     {
         ProfScope ps(c, ZK_K_SUM9, (uint64_t)s->len * 32 * 4);
-        zkk::launch_sum9(s->cur, s->len / 4, c->partials, sums_dev_out, c->stream);
+        zkk::launch_sum9(s->cur, s->len / 4, c->two24, c->deg2_lazy_from_log, c->partials, sums_dev_out, c->stream);
     }
     HIPCHK(c, hipGetLastError());
     return ZK_OK;
@@ -914,7 +913,7 @@ int zk_shard4_fold2(zk_shard4* s, const uint64_t r2[8], void* sums_dev_out) {
     }
     if (sums_dev_out && outlen >= 4) {
         ProfScope ps(c, ZK_K_SUM9, (uint64_t)outlen * 32 * 4);
-        zkk::launch_sum9(dst, outlen / 4, c->partials, sums_dev_out, c->stream);
+        zkk::launch_sum9(dst, outlen / 4, c->two24, c->deg2_lazy_from_log, c->partials, sums_dev_out, c->stream);
     }
     HIPCHK(c, hipGetLastError());
     for (int t = 0; t < 4; ++t) s->cur[t] = dst[t];
@@ -1003,6 +1002,11 @@ int zk_ctx_set_wide_fold(zk_ctx* c, int rounds, int min_log_out, int lds_weights
     c->wide_batch = rounds;
     c->wide_min_log_out = min_log_out;
     c->wide_lds_below_log = lds_weights_below_log;
+    return ZK_OK;
+}
+int zk_ctx_set_deg2_lazy_sums(zk_ctx* c, int from_log) {
+    if (!c || from_log > 62) return ZK_E_ARG;
+    c->deg2_lazy_from_log = from_log;
     return ZK_OK;
 }
 int zk_ctx_set_deg2_rounds_per_pass(zk_ctx* c, int rounds) {
