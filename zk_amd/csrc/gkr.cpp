@@ -11,6 +11,7 @@
 // Both use the degree-2 prover of zkmi.cpp unchanged.  W(u) and W(v) fall out of the last folds and
 // are the next layer's W(r_b), W(r_c) (prover.rs:87-99).
 #include <chrono>
+#include <future>
 
 #include "gkr_kernels.h"
 #include "zkmi_internal.hpp"
@@ -281,10 +282,13 @@ int zk_gkr_prove(zk_ctx* c, zk_circuit* ci, zk_transcript* tr, const zk_mle* inp
     const size_t half_tab = (size_t)1 << zkk::kMaxEqVars;
     const size_t eq_half = std::min(half_tab, std::max(max_in, max_out));
     // scratch: wt[max_out] | Eu[max_in] | A H2 ones T0 T2 T3 [max_in each] | 4 eq half tables
-    DevBuf buf;
     const size_t n_elems = max_out + 7 * max_in + 4 * eq_half;
-    HIPCHK(c, hipMalloc(&buf.p, n_elems * kElem));
-    uint8_t* base = (uint8_t*)buf.p;
+    if (c->gkr_scratch_cap < n_elems * kElem) { // kept in the context between proofs (a few hundred MiB at 2^20 gates per layer)
+        if (c->gkr_scratch) { HIPCHK(c, hipFree(c->gkr_scratch)); c->gkr_scratch = nullptr; c->gkr_scratch_cap = 0; }
+        HIPCHK(c, hipMalloc(&c->gkr_scratch, n_elems * kElem));
+        c->gkr_scratch_cap = n_elems * kElem;
+    }
+    uint8_t* base = (uint8_t*)c->gkr_scratch;
     auto take = [&](size_t n) { void* p = base; base += n * kElem; return p; };
     void* wt = take(max_out);
     void* Eu = take(max_in);
@@ -294,14 +298,35 @@ int zk_gkr_prove(zk_ctx* c, zk_circuit* ci, zk_transcript* tr, const zk_mle* inp
 
     const zk_mle* W0 = ev[L]; // get_w_i(0), :43
     const unsigned k0 = ilog2(W0->len);
+    // proof.output_poly: the copy into the caller's (pageable) buffer runs on a helper thread and its own stream while
+    // this thread feeds the output layer through the Keccak sponge (:46) -- both read W0, neither writes it
+    HIPCHK(c, hipStreamSynchronize(c->stream)); // W0 is complete before the helper stream reads it
+    const int dev = c->device;
+    const void* w0_dev = W0->d;
+    const size_t w0_bytes = W0->len * kElem;
+    std::future<hipError_t> out_copy = std::async(std::launch::async, [dev, w0_dev, w0_bytes, output_poly_out]() -> hipError_t {
+        hipError_t e = hipSetDevice(dev);
+        hipStream_t s2 = nullptr;
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&s2, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipMemcpyAsync(output_poly_out, w0_dev, w0_bytes, hipMemcpyDeviceToHost, s2);
+        if (e == hipSuccess) e = hipStreamSynchronize(s2);
+        if (s2) (void)hipStreamDestroy(s2);
+        return e;
+    });
     rc = stream_le32(c, W0->d, W0->len, [&](const uint8_t* p, size_t nbytes, size_t) { tr->append(p, nbytes); }); // :46
-    if (rc) return rc;
+    {
+        const hipError_t e = out_copy.get(); // joined before any return: the lambda holds no reference to this frame
+        if (rc) return rc;
+        if (e != hipSuccess) {
+            c->err = std::string("output layer download: ") + hipGetErrorString(e);
+            return ZK_E_HIP;
+        }
+    }
     if (layer_ms_out) {
         const auto t_abs = std::chrono::steady_clock::now();
         layer_ms_out[L] = std::chrono::duration<double, std::milli>(t_eval - t_start).count();
         layer_ms_out[L + 1] = std::chrono::duration<double, std::milli>(t_abs - t_eval).count();
     }
-    HIPCHK(c, hipMemcpyAsync(output_poly_out, W0->d, W0->len * kElem, hipMemcpyDeviceToHost, c->stream));
     std::vector<uint64_t> rnd(4 * std::max<size_t>(k0, 1)); // random_values, :49-53
     for (unsigned i = 0; i < k0; ++i) zkh::store(&rnd[4 * i], tr->sample());
 

@@ -79,6 +79,7 @@ void zk_ctx_destroy(zk_ctx* c) {
     if (c->work[0]) (void)hipFree(c->work[0]);
     if (c->work[1]) (void)hipFree(c->work[1]);
     if (c->stage) (void)hipFree(c->stage);
+    if (c->gkr_scratch) (void)hipFree(c->gkr_scratch);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }

@@ -76,6 +76,8 @@ struct zk_ctx {
     void* work[2] = {nullptr, nullptr};
     size_t work_cap[2] = {0, 0}; // bytes
     void* stage = nullptr;       // kChunkElems elements
+    void* gkr_scratch = nullptr; // layer prover's tables (gkr.cpp), kept between proofs: grow-only
+    size_t gkr_scratch_cap = 0;  // bytes
     std::string err;
     bool prof_on = false;
     std::vector<ProfSlot> prof_pending;
