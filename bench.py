@@ -264,9 +264,20 @@ def bench_single(args, ctx, zk_amd, np):
     blocks, iters = 2048, 2000
     ms = ctx.bench_modmul(blocks, iters)
     modmul_per_s = blocks * 256 * iters / (ms * 1e-3)
+    alu = {"modmul_per_s": modmul_per_s, "note": "peak = dependent fq_mul chain, 2048x256 lanes (k_modmul_probe)"}
+    if "multifold_wide" in kernels:  # the wide fold pass: one 10x10-limb inner product (100 v_mad_u64_u32) per input entry
+        k = kernels["multifold_wide"]
+        entries = k["alg_bytes_per_launch"] / 32.0 * 256 / 257
+        alu["fold_pass_limb_mads_per_s"] = 100 * entries / (k["avg_ms"] * 1e-3)
+        alu["fold_pass_products_equiv_frac"] = (entries / (k["avg_ms"] * 1e-3)) / modmul_per_s  # products of 100 of fq_mul's ~270 ops: memory-bound by design
+    if "sum9" in kernels:            # nine-sum sweeps: 18 field products per quarter-index (16 entries of 32 B)
+        k = kernels["sum9"]
+        prod = 18 * k["alg_bytes_per_launch"] * k["launches"] / 512.0
+        alu["sum9_products_per_s"] = prod / (k["total_ms"] * 1e-3)
+        alu["sum9_frac_of_modmul_peak"] = alu["sum9_products_per_s"] / modmul_per_s
     res = {
         "elems_per_s": n / (ms_per_step * 1e-3), "ms_per_step": ms_per_step, "roofline": roofline, "kernels": kernels,
-        "int32_alu": {"modmul_per_s": modmul_per_s, "note": "dependent fq_mul chain, 2048x256 lanes"},
+        "int32_alu": alu,
         "config": {"workload": workload, "log_n": args.log_n, "field": "BN254 Fq",
                    "parallelism": "1 GPU", "transcript": "Keccak-256 on host, one challenge per round"},
     }

@@ -104,3 +104,45 @@ def test_sum2x2_2pow26_config4_size():
     assert ok and np.array_equal(ch, pts)
     vals = [O.mont_to_ints(t.evaluate([c for c in pts]).get_evaluation_points())[0] for t in tabs]
     assert O.mont_to_ints(final)[0] == (vals[0] * vals[1] + vals[2] * vals[3]) % P
+
+
+def test_sumcheck_2pow30_largest_benchmark_size():
+    """The largest table the benchmark range names (2^30 entries, 32 GiB, north_star "2^20-2^30"): two wide passes
+    (8 + 8 rounds) and the m = 4 tail.  The claim is cross-checked against evaluation_sum (another kernel), the proof
+    against the host verifier and the oracle-check evaluation, and against the schedule with the wide passes off."""
+    ctx = zk_amd.Context(0)
+    poly = MLE.generate(SEED + 30, 1 << 30, ctx=ctx)
+    tr = zk_amd.Transcript()
+    tr.append(b"fullsize-2^30")
+    claim, coeffs, ch = zk_amd.SumcheckProver.generate_round_polys(poly, tr)
+    assert coeffs.shape == (30, 2, 4)
+    assert np.array_equal(claim, poly.evaluation_sum())
+    tv = zk_amd.Transcript()
+    tv.append(b"fullsize-2^30")
+    ok, final, ch2 = zk_amd.SumcheckVerifier.partial_verify(zk_amd.SumCheckProof(claim, coeffs), tv)
+    assert ok and np.array_equal(ch, ch2)
+    val = poly.evaluate([c for c in ch]).get_evaluation_points()
+    assert list(val[0]) == list(final)
+    ctx.set_wide_fold(0, 16, 19)          # m = 4 passes only
+    tr1 = zk_amd.Transcript()
+    tr1.append(b"fullsize-2^30")
+    claim1, coeffs1, ch1 = zk_amd.SumcheckProver.generate_round_polys(poly, tr1)
+    assert np.array_equal(claim1, claim) and np.array_equal(coeffs1, coeffs) and np.array_equal(ch1, ch)
+    del poly
+    ctx.close()
+
+
+def test_sum2x2_2pow24_both_nine_sum_kernels_agree():
+    """The unreduced-accumulation sweep (k_sum9_lazy, LDS-DMA ring) and the per-product-reduction sweep give the same
+    proof bytes at a size where the former is the default."""
+    proofs = []
+    for lazy_from in (20, -1):
+        ctx = zk_amd.Context(0)
+        ctx.set_deg2_lazy_sums(lazy_from)
+        tabs = [MLE.generate(SEED + 80 + k, 1 << 24, ctx=ctx) for k in range(4)]
+        f = zk_amd.SumPolynomial([zk_amd.ProductPolynomial(tabs[:2]), zk_amd.ProductPolynomial(tabs[2:])])
+        proof, pts = zk_amd.SumcheckProver.generate_proof_for_partial_verify(O.fq1(0), f, zk_amd.Transcript())
+        proofs.append((proof.round_polys.copy(), pts.copy()))
+        del tabs, f
+        ctx.close()
+    assert np.array_equal(proofs[0][0], proofs[1][0]) and np.array_equal(proofs[0][1], proofs[1][1])

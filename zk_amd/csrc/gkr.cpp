@@ -332,8 +332,13 @@ int zk_gkr_prove(zk_ctx* c, zk_circuit* ci, zk_transcript* tr, const zk_mle* inp
 
     Fq wb = zkh::zero(), wc = zkh::zero();
     size_t coeff_off = 0;
-    hipEvent_t ev_a = nullptr, ev_b = nullptr;
-    if (layer_ms_out) { HIPCHK(c, hipEventCreate(&ev_a)); HIPCHK(c, hipEventCreate(&ev_b)); }
+    struct Events { // destroyed on every exit path
+        hipEvent_t a = nullptr, b = nullptr;
+        ~Events() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+    } evs;
+    if (layer_ms_out) { HIPCHK(c, hipEventCreate(&evs.a)); HIPCHK(c, hipEventCreate(&evs.b)); }
+    hipEvent_t& ev_a = evs.a;
+    hipEvent_t& ev_b = evs.b;
     for (size_t layer_idx = 0; layer_idx < L; ++layer_idx) {
         const LayerDev& Ly = ci->layers[L - 1 - layer_idx];
         const zk_mle* Wn = ev[L - 1 - layer_idx]; // next_w_i, :125
@@ -395,8 +400,6 @@ int zk_gkr_prove(zk_ctx* c, zk_circuit* ci, zk_transcript* tr, const zk_mle* inp
             layer_ms_out[layer_idx] = ms;
         }
     }
-    if (ev_a) (void)hipEventDestroy(ev_a);
-    if (ev_b) (void)hipEventDestroy(ev_b);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return ZK_OK;
 }
