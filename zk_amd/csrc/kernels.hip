@@ -740,6 +740,69 @@ __global__ void __launch_bounds__(192) k_sum9_lazy(Tab4 T, size_t q, fq fix24, f
     }
 }
 
+// The same sums with ONE product per wave: block = (64, 9), wave w = 3 b + a forms U[a][b] for the 64 quarter-indices
+// of the tile.  One unreduced accumulator per lane is ~100 VGPRs = 5 waves per SIMD, so the two 9-wave workgroups of
+// a CU spread 5/5/4/4 over its SIMDs instead of 2/2/1/1 (the 3-wave form loses ~45 % of its VALU time to that
+// imbalance: its waves meet at a barrier every step).  Same tiles, same LDS-DMA ring; waves 0..7 stage two rows each.
+//   partials: [((term * 3 + b) * gridDim.x + bx) * 3 + a]   (as k_sum9_lazy)
+__global__ void __launch_bounds__(576) k_sum9_lazy9(Tab4 T, size_t q, fq fix24, fq* __restrict__ partials) {
+    __shared__ u32x4 sh[3][8][2][64];
+    const int term = blockIdx.y, lane = threadIdx.x;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.y);
+    const int A = w % 3, B = w / 3; // 0, 1, 2 = '+'
+    const fq* __restrict__ F = T.t[2 * term];
+    const fq* __restrict__ G = T.t[2 * term + 1];
+    u64 acc[20];
+#pragma unroll
+    for (int k = 0; k < 20; ++k) acc[k] = 0;
+    const size_t stride = (size_t)gridDim.x * 64, base0 = (size_t)blockIdx.x * 64;
+    const int nt = base0 < q ? (int)((q - base0 + stride - 1) / stride) : 0;
+    auto stage = [&](int t) { // rows 2w, 2w + 1 (= slot w, both halves) for w < 8
+        if (w < 8) {
+            const size_t j = base0 + (size_t)t * stride + lane;
+            const fq* src = ((w & 4) ? G : F) + (size_t)(w & 3) * q + j;
+            u32x4* buf = &sh[t % 3][w][0][0];
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)reinterpret_cast<const u32x4*>(src),
+                                             (__attribute__((address_space(3))) void*)buf, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(reinterpret_cast<const u32x4*>(src) + 1),
+                                             (__attribute__((address_space(3))) void*)(buf + 64), 16, 0, 0);
+        }
+    };
+    if (nt > 0) stage(0);
+    if (nt > 1) stage(1);
+    int since = 0;
+    for (int t = 0; t < nt; ++t) {
+        if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); // leaves tile t+1's two rows in flight (wave 8 has none)
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (t + 2 < nt) stage(t + 2);
+        const u32x4 (&tile)[8][2][64] = sh[t % 3];
+        // operand of factor f: the sum of its entries over b1 in a's set and b2 in b's set (one, two or four entries)
+        auto opnd = [&](int f) -> fq {
+            const int b1lo = A == 1 ? 1 : 0, b2lo = B == 1 ? 1 : 0;
+            fq x = lds_elem(tile[4 * f + 2 * b1lo + b2lo], lane);
+            if (B == 2) x = fq_add_plain(x, lds_elem(tile[4 * f + 2 * b1lo + 1], lane));
+            if (A == 2) {
+                fq y = lds_elem(tile[4 * f + 2 + b2lo], lane);
+                if (B == 2) y = fq_add_plain(y, lds_elem(tile[4 * f + 3], lane));
+                x = fq_add_plain(x, y);
+            }
+            return x;
+        };
+        u32 lf[10], lg[10];
+        fq28_unpack(opnd(0), lf);
+        fq28_unpack(opnd(1), lg);
+        fq28_mac_vv(acc, lf, lg);
+        if (++since == 16) {
+            since = 0;
+            fq28_carry(acc);
+        }
+    }
+    const fq r = fq_wave_sum(fq_mul(fq28_redc(acc), fix24));
+    if (lane == 0) fq_store(&partials[((size_t)(term * 3 + B) * gridDim.x + blockIdx.x) * 3 + A], r);
+}
+
 // U (in[3 b + a], see k_sum9_lazy) -> the nine sums S[3Y + t].  One block of 64 threads.
 __global__ void __launch_bounds__(64) k_sum9_from_u(const fq* __restrict__ in, fq* __restrict__ out) {
     const int s = threadIdx.x;
@@ -1014,6 +1077,9 @@ void launch_sum9(const void* const t[4], size_t q, const uint64_t fix24[4], int 
         size_t gx = (q + 63) / 64;
         if (gx > (size_t)kMaxBlocks9) gx = kMaxBlocks9;
         fq* u = (fq*)partials + (size_t)18 * kMaxBlocks9; // nine U sums, behind the partials
+        static const bool nine = !getenv("ZK_SUM9_LAZY3"); // experiment knob
+        if (nine) hipLaunchKernelGGL(k_sum9_lazy9, dim3((unsigned)gx, 2), dim3(64, 9), 0, st, T, q, to_fq(fix24), (fq*)partials);
+        else
         hipLaunchKernelGGL(k_sum9_lazy, dim3((unsigned)gx, 2), dim3(64, 3), 0, st, T, q, to_fq(fix24), (fq*)partials);
         hipLaunchKernelGGL(k_reduce9, dim3(9), dim3(kThreads), 0, st, (const fq*)partials, (int)gx, 1, u);
         hipLaunchKernelGGL(k_sum9_from_u, dim3(1), dim3(64), 0, st, (const fq*)u, (fq*)out);
