@@ -651,15 +651,14 @@ __global__ void __launch_bounds__(kThreads) k_sum9(Tab4 T, size_t q, fq* __restr
 //   V[a][Y] = U[a][Y] (Y = 0, 1),  V[a][2] = 3 U[a][0] + 6 U[a][1] - 2 U[a][+];   S[3Y + 0] = V[0][Y],  S[3Y + 1] = V[1][Y],
 //   S[3Y + 2] = 2 V[0][Y] + 2 V[1][Y] - V[+][Y]
 // (a quadratic R with R(0), R(1), Q = 4 R(1/2) has leading coefficient 2 R(0) + 2 R(1) - Q and R(2) = 3 R(0) + 6 R(1) - 2 Q).
-// An unreduced accumulator is 20 u64 columns, so a lane can hold three, not nine: block = (64, 3), wave b of a
-// workgroup forms the three products (a = 0, 1, +) of ITS b for the same 64 quarter-indices.  At ~195 VGPRs there are
-// two such workgroups per CU and no registers left for loads in flight: the tiles (64 quarter-indices x 8 entries of
-// the term = 16 KiB) are staged by LDS-DMA (global_load_lds_dwordx4: no VGPR destination) into a ring of three
-// buffers, two tiles in flight under each tile's arithmetic, every entry read from HBM exactly once, all three waves
-// taking their operands from LDS.  (Known limit: 6 waves on 4 SIMDs that meet at a barrier every step run at the pace
-// of the doubly occupied SIMDs, VALU ~55 % busy; forcing 3 waves per SIMD spills into the loop and drains the DMA queue.)  Counted vmcnt + raw s_barrier (cdna_hip_programming.md,
-// "Pipelining across barriers"); `sh` is the kernel's only __shared__ object.
-// The reduction divides by 2^280 instead of 2^256: every lane multiplies its three sums by 2^24 (fix24) once.
+// An unreduced accumulator is 20 u64 columns: ONE product per wave.  Block = (64, 9), wave w = 3 b + a forms U[a][b]
+// for the 64 quarter-indices of a tile; 80 VGPRs, two workgroups (18 waves) per CU.  (A form with three accumulators
+// per lane and 3-wave workgroups measured 3.5 % slower: at ~195 VGPRs its six waves per CU sit 2/2/1/1 on the SIMDs
+// and meet at a barrier every step.)  The tiles (64 quarter-indices x 8 entries of the term = 16 KiB) are staged by
+// LDS-DMA (global_load_lds_dwordx4: no VGPR destination) into a ring of three buffers: two tiles are in flight under
+// each tile's arithmetic, every entry is read from HBM exactly once, and all waves take their operands from LDS.
+// Counted vmcnt + raw s_barrier (cdna_hip_programming.md, "Pipelining across barriers"); `sh` is the kernel's only
+// __shared__ object.  The reduction divides by 2^280 instead of 2^256: every lane multiplies its sum by 2^24 (fix24) once.
 //   q must be a multiple of 64.  partials: [((term * 3 + b) * gridDim.x + bx) * 3 + a]
 __device__ __forceinline__ fq lds_elem(const u32x4 (&slot)[2][64], int lane) {
     const u32x4 lo = slot[0][lane], hi = slot[1][lane];
@@ -668,84 +667,7 @@ __device__ __forceinline__ fq lds_elem(const u32x4 (&slot)[2][64], int lane) {
     for (int w = 0; w < 4; ++w) { x.v[w] = lo[w]; x.v[4 + w] = hi[w]; }
     return x;
 }
-__global__ void __launch_bounds__(192) k_sum9_lazy(Tab4 T, size_t q, fq fix24, fq* __restrict__ partials) {
-    // [ring buffer][slot = 4 f + 2 b1 + b2][half of the element][lane]: one LDS-DMA instruction fills one [half] row
-    __shared__ u32x4 sh[3][8][2][64];
-    const int term = blockIdx.y, lane = threadIdx.x;
-    const int B = __builtin_amdgcn_readfirstlane(threadIdx.y); // one wave per b: make the compiler see it as a scalar
-    const fq* __restrict__ F = T.t[2 * term];
-    const fq* __restrict__ G = T.t[2 * term + 1];
-    u64 a0[20], a1[20], a2[20];
-#pragma unroll
-    for (int k = 0; k < 20; ++k) a0[k] = a1[k] = a2[k] = 0;
-    const size_t stride = (size_t)gridDim.x * 64, base0 = (size_t)blockIdx.x * 64;
-    const int nt = base0 < q ? (int)((q - base0 + stride - 1) / stride) : 0; // tiles of this workgroup (same for its 3 waves)
-    // wave B stages rows B, B + 3, ... of the 16 rows (row = 2 slot + half) of a tile: 6 / 5 / 5 instructions
-    auto stage = [&](int t) {
-        const size_t j = base0 + (size_t)t * stride + lane;
-        u32x4* buf = &sh[t % 3][0][0][0];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const int row = B + 3 * i; // scalar
-            if (row < 16) {
-                const int slot = row >> 1, half = row & 1;
-                const fq* src = ((slot & 4) ? G : F) + (size_t)(slot & 3) * q + j; // entry (b1, b2) of factor f sits 2 b1 + b2 quarters in
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(reinterpret_cast<const u32x4*>(src) + half),
-                                                 (__attribute__((address_space(3))) void*)(buf + row * 64), 16, 0, 0);
-            }
-        }
-    };
-    if (nt > 0) stage(0);
-    if (nt > 1) stage(1);
-    int since = 0;
-    for (int t = 0; t < nt; ++t) {
-        // retire this wave's rows of tile t (leave tile t+1's in flight), then meet the other waves: after the barrier
-        // every row of tile t is in LDS and nobody still reads tile t-1, whose buffer tile t+2 is about to take
-        if (t + 1 < nt) {
-            if (B == 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (t + 2 < nt) stage(t + 2);
-        const u32x4 (&tile)[8][2][64] = sh[t % 3];
-        // this wave's operand of factor f at top-variable value b1
-        auto opnd = [&](int f, int b1) -> fq {
-            if (B < 2) return lds_elem(tile[4 * f + 2 * b1 + B], lane);
-            return fq_add_plain(lds_elem(tile[4 * f + 2 * b1], lane), lds_elem(tile[4 * f + 2 * b1 + 1], lane));
-        };
-        u32 lf[10], lg[10];
-        {
-            const fq x0 = opnd(0, 0), y0 = opnd(1, 0), x1 = opnd(0, 1), y1 = opnd(1, 1);
-            fq28_unpack(x0, lf); fq28_unpack(y0, lg);
-            fq28_mac_vv(a0, lf, lg);
-            fq28_unpack(x1, lf); fq28_unpack(y1, lg);
-            fq28_mac_vv(a1, lf, lg);
-            fq28_unpack(fq_add_plain(x0, x1), lf); fq28_unpack(fq_add_plain(y0, y1), lg);
-            fq28_mac_vv(a2, lf, lg);
-        }
-        if (++since == 16) { // carry before a 17th product lands in the columns
-            since = 0;
-            fq28_carry(a0); fq28_carry(a1); fq28_carry(a2);
-        }
-    }
-    // a * 2^-280 -> Montgomery form needs * 2^24 (one fq_mul per sum and lane, once)
-    fq r[3] = {fq_mul(fq28_redc(a0), fix24), fq_mul(fq28_redc(a1), fix24), fq_mul(fq28_redc(a2), fix24)};
-#pragma unroll
-    for (int t = 0; t < 3; ++t) {
-        fq w = fq_wave_sum(r[t]);
-        if (lane == 0) fq_store(&partials[((size_t)(term * 3 + B) * gridDim.x + blockIdx.x) * 3 + t], w);
-    }
-}
-
-// The same sums with ONE product per wave: block = (64, 9), wave w = 3 b + a forms U[a][b] for the 64 quarter-indices
-// of the tile.  One unreduced accumulator per lane is ~100 VGPRs = 5 waves per SIMD, so the two 9-wave workgroups of
-// a CU spread 5/5/4/4 over its SIMDs instead of 2/2/1/1 (the 3-wave form loses ~45 % of its VALU time to that
-// imbalance: its waves meet at a barrier every step).  Same tiles, same LDS-DMA ring; waves 0..7 stage two rows each.
-//   partials: [((term * 3 + b) * gridDim.x + bx) * 3 + a]   (as k_sum9_lazy)
-__global__ void __launch_bounds__(576) k_sum9_lazy9(Tab4 T, size_t q, fq fix24, fq* __restrict__ partials) {
+__global__ void __launch_bounds__(576) k_sum9_lazy(Tab4 T, size_t q, fq fix24, fq* __restrict__ partials) {
     __shared__ u32x4 sh[3][8][2][64];
     const int term = blockIdx.y, lane = threadIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.y);
@@ -1077,10 +999,7 @@ void launch_sum9(const void* const t[4], size_t q, const uint64_t fix24[4], int 
         size_t gx = (q + 63) / 64;
         if (gx > (size_t)kMaxBlocks9) gx = kMaxBlocks9;
         fq* u = (fq*)partials + (size_t)18 * kMaxBlocks9; // nine U sums, behind the partials
-        static const bool nine = !getenv("ZK_SUM9_LAZY3"); // experiment knob
-        if (nine) hipLaunchKernelGGL(k_sum9_lazy9, dim3((unsigned)gx, 2), dim3(64, 9), 0, st, T, q, to_fq(fix24), (fq*)partials);
-        else
-        hipLaunchKernelGGL(k_sum9_lazy, dim3((unsigned)gx, 2), dim3(64, 3), 0, st, T, q, to_fq(fix24), (fq*)partials);
+        hipLaunchKernelGGL(k_sum9_lazy, dim3((unsigned)gx, 2), dim3(64, 9), 0, st, T, q, to_fq(fix24), (fq*)partials);
         hipLaunchKernelGGL(k_reduce9, dim3(9), dim3(kThreads), 0, st, (const fq*)partials, (int)gx, 1, u);
         hipLaunchKernelGGL(k_sum9_from_u, dim3(1), dim3(64), 0, st, (const fq*)u, (fq*)out);
         return;
