@@ -919,7 +919,7 @@ int launch_multifold_lazy(int m, int group, const void* src, void* dst, size_t L
 // grid for the wide pass: up to 2 * kMaxBlocks workgroups (16 per CU: the kernel runs 4 waves per SIMD)
 static inline int grid_blocks_wide(size_t Lb, int log_ob) {
     size_t per = (Lb + kThreads - 1) / kThreads;
-    size_t cap = (size_t)(2 * kMaxBlocks) >> log_ob;
+    size_t cap = (size_t)(2 * kMaxBlocks) >> log_ob; // 1x ... 8x kMaxBlocks measure the same (5.53 - 5.57 TB/s)
     if (per > cap) per = cap;
     if (per < 1) per = 1;
     return (int)(per << log_ob);
