@@ -482,19 +482,24 @@ int zk_shard_fold(zk_shard* s, int m, const uint64_t* r_mont, int m_next, void* 
     if ((rc = ensure_work(c, s->pass & 1, lout * kElem))) return rc;
     void* dst = c->work[s->pass & 1];
     void* sums = m_next ? sums_dev_out : c->sums_dev;
+    int launched = 0; // workgroups of the pass, < 0: the launcher rejected the shape and launched nothing
     {
         ProfScope ps(c, m > zkk::kMaxLazyBatch ? ZK_K_MULTIFOLD_WIDE : ZK_K_MULTIFOLD, (uint64_t)(lout << m) * 32 + (uint64_t)lout * 32);
         if (m > zkk::kMaxLazyBatch) {
-            zkk::launch_multifold_wide(m, s->cur, dst, lout, r_mont, c->two24, c->wide_w, c->wide_lds_below_log, m_next, c->partials, sums, c->stream);
+            launched = zkk::launch_multifold_wide(m, s->cur, dst, lout, r_mont, c->two24, c->wide_w, c->wide_lds_below_log, m_next, c->partials, sums, c->stream);
         } else if (c->lazy && m >= 2) {
             uint32_t w28[(1 << zkk::kMaxLazyBatch) * 10];
             eq_weights28(r_mont, (unsigned)m, w28);
-            zkk::launch_multifold_lazy(m, c->lazy_group, s->cur, dst, lout, w28, m_next, c->partials, sums, c->stream);
+            launched = zkk::launch_multifold_lazy(m, c->lazy_group, s->cur, dst, lout, w28, m_next, c->partials, sums, c->stream);
         } else {
-            zkk::launch_multifold(m, s->cur, dst, lout, r_mont, m_next, c->double_buffer, c->partials, sums, c->stream);
+            launched = zkk::launch_multifold(m, s->cur, dst, lout, r_mont, m_next, c->double_buffer, c->partials, sums, c->stream);
         }
     }
     HIPCHK(c, hipGetLastError());
+    if (launched < 0) {
+        c->err = "fold pass: shape not supported by the kernel";
+        return ZK_E_ARG;
+    }
     s->cur = dst;
     s->ell = ell_out;
     ++s->pass;
