@@ -111,7 +111,12 @@ def test_device_shard_steps_match_oracle():
         assert np.array_equal(got[b], O.mle_sum(t[b * q:(b + 1) * q]))
     assert sh.vars_left() == 8
     with pytest.raises(zk_amd.ZkError):
-        sh.fold(4, O.gen_table(1, 0, 4), 5, buf)  # more block sums than a pass supports
+        sh.fold(4, O.gen_table(1, 0, 4), 5, buf)  # 4 + 5 > 8 variables left (and buf holds 16 sums)
+    big = sh.new_sums(512)
+    with pytest.raises(zk_amd.ZkError):
+        sh.block_sums(9, big)  # more rounds than one pass can bind (8)
+    assert sh.next_batch() == 4 and sh.next_batch(6) == 2 and sh.next_batch(8) == 0  # the default schedule on a small table
+    assert np.array_equal(sh.table().cpu().numpy().view(np.uint64), t)               # the folded local table, as gathered
     sh.fold(3, r, 4, buf)  # 8 -> 5 variables left
     assert sh.vars_left() == 5
     with pytest.raises(zk_amd.ZkError):
