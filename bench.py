@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--wide-batch", type=int, default=-1, help="rounds bound by a pass over a large table (5..8, 0 = off, -1 = library default 8)")
     ap.add_argument("--wide-min-log-out", type=int, default=16, help="wide passes are taken while the folded table keeps >= 2^k entries")
     ap.add_argument("--wide-lds-below", type=int, default=19, help="wide passes with < 2^k outputs make their weights per workgroup in LDS")
+    ap.add_argument("--tail-max-log", type=int, default=-1, help="tables of <= 2^k entries bind eight rounds per pass (0 = off, -1 = library default 16)")
+    ap.add_argument("--tail-out-below", type=int, default=13, help="passes with < 2^k outputs use one wave per output")
     ap.add_argument("--fold-variant", type=int, default=0, help="0 eq-weight inner product, 1 tree, 2 tree+double buffer")
     ap.add_argument("--deg2-rounds", type=int, default=0, help="degree-2 prover: rounds per device pass (1 or 2; 0 = library default, 2)")
     ap.add_argument("--gather-log", type=int, default=13, help="multi-GPU: local tables of <= 2^k entries are all-gathered and finished on every rank (-1 = sharded to the end)")
@@ -149,6 +151,8 @@ def main():
             ctx.set_fold_batch(args.fold_batch, args.fold_variant)
         if args.wide_batch >= 0:
             ctx.set_wide_fold(args.wide_batch, args.wide_min_log_out, args.wide_lds_below)
+        if args.tail_max_log >= 0:
+            ctx.set_tail_fold(args.tail_max_log, args.tail_out_below)
         result = bench_single(args, ctx, zk_amd, np)
 
     torch.cuda.synchronize()
@@ -312,6 +316,8 @@ def bench_sharded(args, zk_amd, np, dist, rank, local_rank, world):
         ctx.set_fold_batch(args.fold_batch, args.fold_variant)
     if args.wide_batch >= 0:
         ctx.set_wide_fold(args.wide_batch, args.wide_min_log_out, args.wide_lds_below)
+    if args.tail_max_log >= 0:
+        ctx.set_tail_fold(args.tail_max_log, args.tail_out_below)
     gather_log = args.gather_log if args.gather_log >= 0 else None
     fold_batch = None  # the library's schedule (zk_shard_next_batch): the same passes as the single-GPU prover
     base = zk_amd.Transcript()

@@ -269,6 +269,10 @@ int zk_ctx_set_fold_batch(zk_ctx *ctx, int rounds_per_pass, int variant);
  * fewer than 2^k outputs derive their weights per workgroup in LDS (one launch, latency matters), larger ones
  * read them from a small device buffer as scalar loads (4 waves per SIMD).  Proof bytes do not depend on any of it. */
 int zk_ctx_set_wide_fold(zk_ctx *ctx, int rounds, int min_log_out, int lds_weights_below_log);
+/* The tail of a prove: tables of at most 2^max_log_table entries (default 16; 0 = off) bind eight rounds per pass, and
+ * passes whose output has fewer than 2^out_below_log entries (default 13) form each output with one wave instead of
+ * one lane -- eight rounds at the latency of one.  Proof bytes do not depend on it. */
+int zk_ctx_set_tail_fold(zk_ctx *ctx, int max_log_table, int out_below_log);
 /* Rounds bound per device pass by the degree-2 prover: 2 (default; nine sums serve two rounds) or 1 (one
  * evaluation triple per pass).  Proof bytes do not depend on it. */
 int zk_ctx_set_deg2_rounds_per_pass(zk_ctx *ctx, int rounds);

@@ -104,6 +104,7 @@ def test_sumcheck_2pow28_headline_size():
     val = poly.evaluate([c for c in ch]).get_evaluation_points()
     assert list(val[0]) == list(final)
     ctx.set_fold_batch(1, 1)              # one round per pass, fold tree: a different schedule and kernel
+    ctx.set_tail_fold(0)
     tr1 = zk_amd.Transcript()
     tr1.append(b"fullsize-2^28")
     claim1, coeffs1, ch1 = zk_amd.SumcheckProver.generate_round_polys(poly, tr1)
@@ -144,6 +145,7 @@ def test_sumcheck_2pow30_largest_benchmark_size():
     val = poly.evaluate([c for c in ch]).get_evaluation_points()
     assert list(val[0]) == list(final)
     ctx.set_wide_fold(0, 16, 19)          # m = 4 passes only
+    ctx.set_tail_fold(0)
     tr1 = zk_amd.Transcript()
     tr1.append(b"fullsize-2^30")
     claim1, coeffs1, ch1 = zk_amd.SumcheckProver.generate_round_polys(poly, tr1)

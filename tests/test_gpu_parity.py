@@ -162,6 +162,7 @@ def test_sumcheck_every_fold_batch_setting_gives_the_same_proof(batch, db):
     """Rounds-per-pass batching is an execution schedule, not a protocol change: proofs are identical."""
     c = zk_amd.Context(0)
     c.set_fold_batch(batch, db)
+    c.set_tail_fold(0)  # the default schedule would take tables this small through eight-round tail passes instead
     for log_n in (1, 2, 3, 4, 5, 6, 7, 9, 13, 17):
         table = O.gen_table(SEED + 60 + log_n, 0, 1 << log_n)
         poly = MLE(table, ctx=c)
@@ -174,12 +175,34 @@ def test_sumcheck_every_fold_batch_setting_gives_the_same_proof(batch, db):
         c.set_fold_batch(9, 0)
 
 
+@pytest.mark.parametrize("max_log,out_below,fold_batch", [(20, 13, 4), (20, 3, 4), (20, 0, 4), (12, 13, 3), (20, 20, 2), (9, 13, 1), (20, 13, 8)])
+def test_sumcheck_tail_passes_give_the_same_proof(max_log, out_below, fold_batch):
+    """The tail schedule (eight rounds per pass on small tables, one wave per output when the output is tiny, a last
+    batch of up to eight rounds straight from the block sums) against the oracle, for every table size it touches."""
+    c = zk_amd.Context(0)
+    c.set_fold_batch(fold_batch, 0)
+    c.set_tail_fold(max_log, out_below)
+    for log_n in range(1, 21):
+        table = O.gen_table(SEED + 120 + log_n, 0, 1 << log_n)
+        poly = MLE(table, ctx=c)
+        proof, ch = zk_amd.SumcheckProver.generate_sumcheck_proof(poly, return_challenges=True)
+        oclaim, ocoeffs, och = O.sumcheck_prove(table) if log_n <= 16 else O.sumcheck_prove_fast(table)
+        assert list(proof.initial_claim_sum) == list(oclaim), (max_log, out_below, fold_batch, log_n)
+        assert np.array_equal(proof.round_polys, ocoeffs), (max_log, out_below, fold_batch, log_n)
+        assert np.array_equal(ch, och), (max_log, out_below, fold_batch, log_n)
+        pts = [r for r in ch]
+        assert np.array_equal(poly.evaluate(pts).get_evaluation_points(), O.mle_evaluate(table, pts)) if log_n <= 14 else True
+    with pytest.raises(zk_amd.ZkError):
+        c.set_tail_fold(41, 13)
+
+
 @pytest.mark.parametrize("wide,min_log_out,lds_below", [(8, 2, 19), (8, 5, 0), (7, 3, 0), (6, 0, 64), (5, 4, 0), (0, 17, 19), (8, 3, 12), (6, 1, 0)])
 def test_sumcheck_wide_first_passes_give_the_same_proof(wide, min_log_out, lds_below):
     """The pass schedule (wide 2^m-stream passes while the table is large, the default batch after that) is not
     part of the protocol: the thresholds are lowered here so that small tables take one or more wide passes."""
     c = zk_amd.Context(0)
     c.set_wide_fold(wide, min_log_out, lds_below)  # lds_below = 0: the scalar-weight kernel on every wide pass
+    c.set_tail_fold(0)
     for log_n in (4, 9, 10, 11, 13, 16, 18):
         table = O.gen_table(SEED + 80 + log_n, 0, 1 << log_n)
         poly = MLE(table, ctx=c)

@@ -268,7 +268,7 @@ int main(int argc, char** argv) {
         for (int i = 0; i < 32; ++i) r[i] = 0x0123456789abcdefull >> (i % 4 == 3 ? 8 : 0);
         const size_t lo = n >> m;
         for (int log_ob : {4, 8}) {
-            float ms = timeit([&] { launch_multifold_wide(m, src, dst, lo, r, two24, wbuf, 19, log_ob, part, sums, 0); }, a, b);
+            float ms = timeit([&] { launch_multifold_wide(m, src, dst, lo, r, two24, wbuf, 19, 0, log_ob, part, sums, 0); }, a, b);
             printf("real launch_multifold_wide m = %d (%3d streams), %3d output blocks: %8.1f GB/s (%.3f ms)\n", m, 1 << m, 1 << log_ob,
                    ((double)n * 32 + (double)lo * 32) / ms / 1e6, ms);
         }

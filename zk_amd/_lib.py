@@ -98,6 +98,7 @@ SYMBOLS = [
     ("zk_gkr_verify", C.c_int, [_VP, _VP, _VP, _VP, u64p, C.c_size_t, u64p, u64p, u64p, C.POINTER(C.c_int)]),
     ("zk_ctx_set_fold_batch", C.c_int, [_VP, C.c_int, C.c_int]),
     ("zk_ctx_set_wide_fold", C.c_int, [_VP, C.c_int, C.c_int, C.c_int]),
+    ("zk_ctx_set_tail_fold", C.c_int, [_VP, C.c_int, C.c_int]),
     ("zk_ctx_set_deg2_rounds_per_pass", C.c_int, [_VP, C.c_int]),
     ("zk_ctx_set_deg2_lazy_sums", C.c_int, [_VP, C.c_int]),
     ("zk_prof_enable", C.c_int, [_VP, C.c_int]),

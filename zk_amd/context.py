@@ -43,6 +43,11 @@ class Context:
         workgroup in LDS, larger ones read them as scalar loads.  Proof bytes do not depend on it."""
         check(lib().zk_ctx_set_wide_fold(self.h, rounds, min_log_out, lds_weights_below_log))
 
+    def set_tail_fold(self, max_log_table: int = 16, out_below_log: int = 13):
+        """Tables of <= 2^max_log_table entries bind eight rounds per pass (0 = off); passes with fewer than
+        2^out_below_log outputs use one wave per output.  Proof bytes do not depend on it."""
+        check(lib().zk_ctx_set_tail_fold(self.h, max_log_table, out_below_log))
+
     def set_deg2_rounds_per_pass(self, rounds: int):
         """Degree-2 prover schedule: 2 rounds per device pass (default) or 1.  Proof bytes do not depend on it."""
         check(lib().zk_ctx_set_deg2_rounds_per_pass(self.h, rounds))

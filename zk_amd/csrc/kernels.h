@@ -31,8 +31,9 @@ int launch_multifold_lazy(int m, int group, const void* src, void* dst, size_t L
 // (Montgomery).  Outputs below 2^lds_below_log entries: per workgroup in LDS (one launch); larger ones: by a one-workgroup
 // kernel into wbuf (device, kWideWeightWords u32), read as scalar loads.  partials must hold 2 * kMaxBlocks elements
 static constexpr int kWideWeightWords = (1 << kMaxFoldBatch) * 10;
+// Outputs below 2^coop_below_log entries (m >= 6): one wave per output (k_multifold_coop); 0 = never.
 int launch_multifold_wide(int m, const void* src, void* dst, size_t Lout, const uint64_t* r, const uint64_t two24[4], void* wbuf,
-                          int lds_below_log, int log_ob, void* partials, void* out, hipStream_t st);
+                          int lds_below_log, int coop_below_log, int log_ob, void* partials, void* out, hipStream_t st);
 void launch_fold_var(const void* src, void* dst, size_t n_out, int log_s, const uint64_t r[4], hipStream_t st);
 void launch_reduce_partials(const void* partials, int nblocks, int ns, void* out, hipStream_t st);
 int launch_sum_all(const void* T, size_t n, void* partials, hipStream_t st);

@@ -9,6 +9,7 @@
 // All kernels are HBM-streaming integer kernels: no LDS tiling (no reuse), no MFMA.  Grids are
 // capped at kMaxBlocks x 256 threads and grid-stride, block -> per-block partial sums, one
 // small second-stage kernel folds the partials (fixed order: results are bit-reproducible).
+#include <algorithm>
 #include <cstdlib>
 #include "fq_dev.hpp"
 #include "kernels.h"
@@ -451,6 +452,80 @@ __global__ void __launch_bounds__(kThreads) k_multifold_wide_lds(const fq* __res
         if (big) fq_store_stream(dst + j0 + i, o); else fq_store(dst + j0 + i, o);
         acc1[0] = fq_add(acc1[0], o);
         i = n;
+    }
+    block_sum_store<1>(acc1, partials);
+}
+
+// The same pass for TINY outputs (a few thousand entries or fewer: the tail of every prove).  With one lane per output
+// each lane walks its 2^m inputs alone and the pass costs 2^m / 8 dependent load round trips, so the tail used to be
+// cut into m = 4 passes -- five of them (and five host round trips) between 2^20 entries and the end.  Here ONE WAVE
+// forms one output: lane l takes inputs b = l, l + 64, ... (2^m / 64 of them, m = 6..8), the 64 unreduced partial
+// sums are carried and added across the wave by a butterfly of shuffles, and a single reduction gives the output.
+// Eight rounds per pass at the latency of one: 2^20 -> 2^12 -> 2^4 in two passes.  Weights per workgroup in LDS as
+// in k_multifold_wide_lds (each lane reads ITS weights: stride-10 addresses, two-way bank conflicts at worst).
+__global__ void __launch_bounds__(kThreads) k_multifold_coop(const fq* __restrict__ src, fq* __restrict__ dst, size_t Lout, ChalWide ch, int m,
+                                                              int log_ob, fq* __restrict__ partials) {
+    __shared__ fq eq[1 << kMaxFoldBatch];
+    __shared__ u32 wl[(1 << kMaxFoldBatch) * 10];
+    if (threadIdx.x == 0) eq[0] = ch.two24;
+    __syncthreads();
+#pragma unroll
+    for (int l = 0; l < kMaxFoldBatch; ++l) {
+        if (l < m) {
+            const bool act = (int)threadIdx.x < (1 << l);
+            fq v, hi;
+            if (act) {
+                v = eq[threadIdx.x];
+                hi = fq_mul(v, ch.r[l]);
+            }
+            __syncthreads();
+            if (act) {
+                eq[2 * threadIdx.x + 1] = hi;
+                eq[2 * threadIdx.x] = fq_sub(v, hi);
+            }
+            __syncthreads();
+        }
+    }
+    if ((int)threadIdx.x < (1 << m)) {
+        u32 l28[10];
+        fq28_unpack(eq[threadIdx.x], l28);
+#pragma unroll
+        for (int j = 0; j < 10; ++j) wl[threadIdx.x * 10 + j] = l28[j];
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int per = 1 << (m - 6); // inputs per lane: 1, 2 or 4
+    const unsigned gpb = gridDim.x >> log_ob;
+    const unsigned c = blockIdx.x / gpb, wi = blockIdx.x % gpb;
+    const size_t Lb = Lout >> log_ob;
+    const size_t j0 = (size_t)c * Lb;
+    fq acc1[1] = {fq_zero()};
+    for (size_t i = (size_t)wi * (kThreads / 64) + wave; i < Lb; i += (size_t)gpb * (kThreads / 64)) { // wave-uniform
+        fq x[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (k < per) x[k] = fq_load(src + (size_t)(lane + 64 * k) * Lout + j0 + i);
+        u64 acc[20];
+#pragma unroll
+        for (int k = 0; k < 20; ++k) acc[k] = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (k < per) fq28_mac(acc, x[k], wl + (lane + 64 * k) * 10);
+        fq28_carry(acc); // columns below 2^28 (+ the tiny top one): 64 of them add up below 2^35
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+            for (int k = 0; k < 20; ++k) {
+                const u32 lo = __shfl_xor((u32)acc[k], off, 64), hi = __shfl_xor((u32)(acc[k] >> 32), off, 64);
+                acc[k] += ((u64)hi << 32) | lo;
+            }
+        }
+        const fq o = fq28_redc(acc); // every lane holds the same sums
+        if (lane == 0) {
+            fq_store(dst + j0 + i, o);
+            acc1[0] = fq_add(acc1[0], o);
+        }
     }
     block_sum_store<1>(acc1, partials);
 }
@@ -925,11 +1000,20 @@ static inline int grid_blocks_wide(size_t Lb, int log_ob) {
     return (int)(per << log_ob);
 }
 int launch_multifold_wide(int m, const void* src, void* dst, size_t Lout, const uint64_t* r, const uint64_t two24[4], void* wbuf,
-                          int lds_below_log, int log_ob, void* partials, void* out, hipStream_t st) {
+                          int lds_below_log, int coop_below_log, int log_ob, void* partials, void* out, hipStream_t st) {
     if (m < 3 || m > kMaxFoldBatch || (Lout >> log_ob) >= ((size_t)1 << 31)) return -1;
     ChalWide ch;
     for (int l = 0; l < kMaxFoldBatch; ++l) ch.r[l] = l < m ? to_fq(r + 4 * l) : fq{};
     ch.two24 = to_fq(two24);
+    if (coop_below_log > 0 && m >= 6 && Lout < ((size_t)1 << std::min(coop_below_log, 40))) { // tiny output: one wave per output
+        size_t per = ((Lout >> log_ob) + 3) / 4, cap = (size_t)kMaxBlocks >> log_ob;
+        if (per > cap) per = cap;
+        if (per < 1) per = 1;
+        const int g = (int)(per << log_ob);
+        hipLaunchKernelGGL(k_multifold_coop, dim3(g), dim3(kThreads), 0, st, (const fq*)src, (fq*)dst, Lout, ch, m, log_ob, (fq*)partials);
+        hipLaunchKernelGGL(k_reduce_groups, dim3(1 << log_ob), dim3(kThreads), 0, st, (const fq*)partials, g >> log_ob, (fq*)out);
+        return g;
+    }
     if (lds_below_log > 0 && (lds_below_log >= 63 || Lout < ((size_t)1 << lds_below_log))) { // small output: weights per workgroup in LDS
         int g = grid_blocks(Lout >> log_ob, log_ob);
         hipLaunchKernelGGL(k_multifold_wide_lds, dim3(g), dim3(kThreads), 0, st, (const fq*)src, (fq*)dst, Lout, ch, m, log_ob, (fq*)partials);

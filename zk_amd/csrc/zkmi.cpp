@@ -486,7 +486,7 @@ int zk_shard_fold(zk_shard* s, int m, const uint64_t* r_mont, int m_next, void* 
     {
         ProfScope ps(c, m > zkk::kMaxLazyBatch ? ZK_K_MULTIFOLD_WIDE : ZK_K_MULTIFOLD, (uint64_t)(lout << m) * 32 + (uint64_t)lout * 32);
         if (m > zkk::kMaxLazyBatch) {
-            launched = zkk::launch_multifold_wide(m, s->cur, dst, lout, r_mont, c->two24, c->wide_w, c->wide_lds_below_log, m_next, c->partials, sums, c->stream);
+            launched = zkk::launch_multifold_wide(m, s->cur, dst, lout, r_mont, c->two24, c->wide_w, c->wide_lds_below_log, c->tail_max_log > 0 ? c->tail_out_below_log : 0, m_next, c->partials, sums, c->stream);
         } else if (c->lazy && m >= 2) {
             uint32_t w28[(1 << zkk::kMaxLazyBatch) * 10];
             eq_weights28(r_mont, (unsigned)m, w28);
@@ -1008,6 +1008,12 @@ int zk_ctx_set_wide_fold(zk_ctx* c, int rounds, int min_log_out, int lds_weights
     c->wide_batch = rounds;
     c->wide_min_log_out = min_log_out;
     c->wide_lds_below_log = lds_weights_below_log;
+    return ZK_OK;
+}
+int zk_ctx_set_tail_fold(zk_ctx* c, int max_log_table, int out_below_log) {
+    if (!c || max_log_table < 0 || max_log_table > 40 || out_below_log < 0 || out_below_log > 40) return ZK_E_ARG;
+    c->tail_max_log = max_log_table;
+    c->tail_out_below_log = out_below_log;
     return ZK_OK;
 }
 int zk_ctx_set_deg2_lazy_sums(zk_ctx* c, int from_log) {

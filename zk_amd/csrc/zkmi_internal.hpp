@@ -66,6 +66,8 @@ struct zk_ctx {
     int fold_batch = 4;          // rounds bound per device pass (1..kMaxFoldBatch)
     int wide_batch = 8;          // rounds bound by a pass over a LARGE table (0: never; kernels.hip, k_multifold_wide) ...
     int wide_lds_below_log = 19; // wide passes with fewer than 2^k outputs derive their weights per workgroup in LDS (one launch)
+    int tail_max_log = 16;       // tables of <= 2^k entries: eight rounds per pass with one wave per output (k_multifold_coop); 0: off
+    int tail_out_below_log = 13; // ... used by passes whose output has fewer than 2^k entries
     int wide_min_log_out = 16;   // ... taken while its output keeps at least 2^wide_min_log_out entries
     bool double_buffer = false;  // register double-buffering in k_multifold (tree variant)
     bool lazy = true;            // inner-product form with one reduction per output (k_multifold_lazy)
@@ -125,6 +127,10 @@ inline unsigned next_batch(const zk_ctx* c, unsigned ell) {
         const unsigned w = std::min((unsigned)c->wide_batch, ell - (unsigned)c->wide_min_log_out);
         if (w >= (unsigned)c->fold_batch + 2 || w == (unsigned)c->wide_batch) return w;
     }
+    // the tail: eight rounds per pass (one wave per output), and a last batch of up to eight rounds straight from the
+    // block sums (no fold pass follows it)
+    if (c->tail_max_log > 0 && ell <= (unsigned)c->tail_max_log && ell > (unsigned)c->fold_batch)
+        return std::min((unsigned)zkk::kMaxFoldBatch, ell);
     return std::min((unsigned)c->fold_batch, ell);
 }
 
