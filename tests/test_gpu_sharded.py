@@ -115,7 +115,10 @@ def test_device_shard_steps_match_oracle():
     big = sh.new_sums(512)
     with pytest.raises(zk_amd.ZkError):
         sh.block_sums(9, big)  # more rounds than one pass can bind (8)
-    assert sh.next_batch() == 4 and sh.next_batch(6) == 2 and sh.next_batch(8) == 0  # the default schedule on a small table
+    assert sh.next_batch() == 8 and sh.next_batch(6) == 2 and sh.next_batch(8) == 0  # the default schedule on a small table: one batch
+    ctx.set_tail_fold(0)
+    assert sh.next_batch() == 4 and sh.next_batch(5) == 3
+    ctx.set_tail_fold()
     assert np.array_equal(sh.table().cpu().numpy().view(np.uint64), t)               # the folded local table, as gathered
     sh.fold(3, r, 4, buf)  # 8 -> 5 variables left
     assert sh.vars_left() == 5
