@@ -246,7 +246,7 @@ def bench_single(args, ctx, zk_amd, np):
     ms_per_step = dt * 1e3 / args.steps
 
     kernels = {}
-    for name in ("block_sums", "multifold_wide", "multifold", "eval3", "fold4_eval3", "sum9", "fold2x4_sum9"):
+    for name in ("block_sums", "multifold_wide", "multifold", "multifold_tail", "eval3", "fold4_eval3", "sum9", "fold2x4_sum9"):
         p = ctx.prof_read(name)
         if p["launches"]:
             kernels[name] = {
@@ -332,7 +332,7 @@ def bench_sharded(args, zk_amd, np, dist, rank, local_rank, world):
             finally:
                 sh.close()
 
-        dom_kernel, names = "multifold", ("block_sums", "multifold_wide", "multifold")
+        dom_kernel, names = "multifold", ("block_sums", "multifold_wide", "multifold", "multifold_tail")
         what = f"single-MLE sumcheck, 2^{log_total} entries"
         exchange = f"all-gather of 2^m block sums per pass ({dist.get_backend()}), library pass schedule; tables of <= 2^{args.gather_log} entries per rank all-gathered and finished on every rank"
     else:

@@ -5,7 +5,7 @@ import ctypes as C
 
 from ._lib import check, lib
 
-KERNELS = {"block_sums": 0, "multifold": 1, "fold": 2, "eval3": 3, "fold4_eval3": 4, "sum9": 5, "fold2x4_sum9": 6, "multifold_wide": 7}
+KERNELS = {"block_sums": 0, "multifold": 1, "fold": 2, "eval3": 3, "fold4_eval3": 4, "sum9": 5, "fold2x4_sum9": 6, "multifold_wide": 7, "multifold_tail": 8}
 
 
 class Context:

@@ -484,7 +484,9 @@ int zk_shard_fold(zk_shard* s, int m, const uint64_t* r_mont, int m_next, void* 
     void* sums = m_next ? sums_dev_out : c->sums_dev;
     int launched = 0; // workgroups of the pass, < 0: the launcher rejected the shape and launched nothing
     {
-        ProfScope ps(c, m > zkk::kMaxLazyBatch ? ZK_K_MULTIFOLD_WIDE : ZK_K_MULTIFOLD, (uint64_t)(lout << m) * 32 + (uint64_t)lout * 32);
+        const bool tail = m >= 6 && c->tail_max_log > 0 && lout < ((size_t)1 << c->tail_out_below_log); // as launch_multifold_wide decides
+        ProfScope ps(c, m <= zkk::kMaxLazyBatch ? ZK_K_MULTIFOLD : tail ? ZK_K_MULTIFOLD_TAIL : ZK_K_MULTIFOLD_WIDE,
+                     (uint64_t)(lout << m) * 32 + (uint64_t)lout * 32);
         if (m > zkk::kMaxLazyBatch) {
             launched = zkk::launch_multifold_wide(m, s->cur, dst, lout, r_mont, c->two24, c->wide_w, c->wide_lds_below_log, c->tail_max_log > 0 ? c->tail_out_below_log : 0, m_next, c->partials, sums, c->stream);
         } else if (c->lazy && m >= 2) {
