@@ -285,38 +285,51 @@ struct ChalWide {
     fq two24; // 2^24 in Montgomery form: eq * 2^256 -> eq * 2^280 (fq28_redc divides by 2^280)
 };
 
-// wout[b * 10 + j] = limb j of eq(r, b) * 2^280 mod p, b < 2^m; challenge l sits on bit m-1-l of b.  One workgroup.
-__global__ void __launch_bounds__(kThreads) k_eq_weights28(ChalWide ch, int m, u32* __restrict__ wout) {
-    __shared__ fq eq[1 << kMaxFoldBatch];
-    if (threadIdx.x == 0) {
-        eq[0] = ch.two24; // the tree is linear in its root: every weight comes out multiplied by 2^24
+// wout[b * 10 + j] = limb j of eq(r, b) * 2^280 mod p, b < 2^m (3 <= m <= 8); challenge l sits on bit m-1-l of b.
+// By one workgroup of kThreads: the trees of the top m/2 and of the remaining variables are built side by side
+// (threads 0-15 and 16-31; level l appends variable l as the new least significant bit; the top tree's root is 2^24,
+// so every weight comes out multiplied by it) and one product per weight joins them: m/2 + 1 dependent products (5 at
+// m = 8) instead of m + 1 -- this chain is on the critical path of every wide and tail pass.
+__device__ __forceinline__ fq chal_pick(const ChalWide& ch, int idx) { // ch.r[idx] without dynamic indexing of kernel arguments
+    fq r = ch.r[0];
+#pragma unroll
+    for (int k = 1; k < kMaxFoldBatch; ++k)
+        if (idx == k) r = ch.r[k];
+    return r;
+}
+__device__ __forceinline__ void eq_weights28_block(const ChalWide& ch, int m, u32* wout) {
+    __shared__ fq half[2][16];
+    const int mh = m >> 1, ml = m - mh; // 1 <= mh <= ml <= 4
+    const int t = threadIdx.x & 15, side = (threadIdx.x >> 4) & 1;
+    const bool builder = threadIdx.x < 32;
+    if (builder && t == 0) {
+        const fq one = {FQ_R_LIMBS};
+        half[side][0] = side ? one : ch.two24;
     }
     __syncthreads();
-    // level l appends variable l as the new least significant bit
 #pragma unroll
-    for (int l = 0; l < kMaxFoldBatch; ++l) {
-        if (l < m) {
-            const bool act = (int)threadIdx.x < (1 << l);
-            fq v, hi;
-            if (act) {
-                v = eq[threadIdx.x];
-                hi = fq_mul(v, ch.r[l]);
-            }
-            __syncthreads();
-            if (act) {
-                eq[2 * threadIdx.x + 1] = hi;
-                eq[2 * threadIdx.x] = fq_sub(v, hi);
-            }
-            __syncthreads();
+    for (int l = 0; l < 4; ++l) {
+        const bool act = builder && l < (side ? ml : mh) && t < (1 << l);
+        fq v, hi;
+        if (act) {
+            v = half[side][t];
+            hi = fq_mul(v, chal_pick(ch, side ? mh + l : l));
         }
+        __syncthreads();
+        if (act) {
+            half[side][2 * t + 1] = hi;
+            half[side][2 * t] = fq_sub(v, hi);
+        }
+        __syncthreads();
     }
     if ((int)threadIdx.x < (1 << m)) {
         u32 l28[10];
-        fq28_unpack(eq[threadIdx.x], l28);
+        fq28_unpack(fq_mul(half[0][threadIdx.x >> ml], half[1][threadIdx.x & ((1 << ml) - 1)]), l28);
 #pragma unroll
-        for (int j = 0; j < 10; ++j) wout[threadIdx.x * 10 + j] = l28[j];
+        for (int j2 = 0; j2 < 10; ++j2) wout[threadIdx.x * 10 + j2] = l28[j2];
     }
 }
+__global__ void __launch_bounds__(kThreads) k_eq_weights28(ChalWide ch, int m, u32* __restrict__ wout) { eq_weights28_block(ch, m, wout); }
 
 template <bool BIG> // BIG: the output is beyond the caches: streaming stores
 __global__ void __launch_bounds__(kThreads) k_multifold_wide(const fq* __restrict__ src, fq* __restrict__ dst, size_t Lout,
@@ -378,37 +391,9 @@ __global__ void __launch_bounds__(kThreads) k_multifold_wide(const fq* __restric
 __global__ void __launch_bounds__(kThreads) k_multifold_wide_lds(const fq* __restrict__ src, fq* __restrict__ dst, size_t Lout, ChalWide ch, int m,
                                                               int log_ob, fq* __restrict__ partials) {
     constexpr int G = 4;
-    __shared__ fq eq[1 << kMaxFoldBatch];
     __shared__ u32 wl[(1 << kMaxFoldBatch) * 10];
     const int nb = 1 << m, ng = nb / G; // m >= 3: ng is even
-    if (threadIdx.x == 0) {
-        eq[0] = ch.two24; // the tree is linear in its root: every weight comes out multiplied by 2^24
-    }
-    __syncthreads();
-    // eq(r, b), challenge l on bit m-1-l of b: level l appends variable l as the new least significant bit
-#pragma unroll
-    for (int l = 0; l < kMaxFoldBatch; ++l) {
-        if (l < m) {
-            const bool act = (int)threadIdx.x < (1 << l);
-            fq v, hi;
-            if (act) {
-                v = eq[threadIdx.x];
-                hi = fq_mul(v, ch.r[l]);
-            }
-            __syncthreads();
-            if (act) {
-                eq[2 * threadIdx.x + 1] = hi;
-                eq[2 * threadIdx.x] = fq_sub(v, hi);
-            }
-            __syncthreads();
-        }
-    }
-    if ((int)threadIdx.x < nb) {
-        u32 l28[10];
-        fq28_unpack(eq[threadIdx.x], l28);
-#pragma unroll
-        for (int j = 0; j < 10; ++j) wl[threadIdx.x * 10 + j] = l28[j];
-    }
+    eq_weights28_block(ch, m, wl);
     __syncthreads();
 
     const unsigned gpb = gridDim.x >> log_ob;
@@ -465,33 +450,8 @@ __global__ void __launch_bounds__(kThreads) k_multifold_wide_lds(const fq* __res
 // in k_multifold_wide_lds (each lane reads ITS weights: stride-10 addresses, two-way bank conflicts at worst).
 __global__ void __launch_bounds__(kThreads) k_multifold_coop(const fq* __restrict__ src, fq* __restrict__ dst, size_t Lout, ChalWide ch, int m,
                                                               int log_ob, fq* __restrict__ partials) {
-    __shared__ fq eq[1 << kMaxFoldBatch];
     __shared__ u32 wl[(1 << kMaxFoldBatch) * 10];
-    if (threadIdx.x == 0) eq[0] = ch.two24;
-    __syncthreads();
-#pragma unroll
-    for (int l = 0; l < kMaxFoldBatch; ++l) {
-        if (l < m) {
-            const bool act = (int)threadIdx.x < (1 << l);
-            fq v, hi;
-            if (act) {
-                v = eq[threadIdx.x];
-                hi = fq_mul(v, ch.r[l]);
-            }
-            __syncthreads();
-            if (act) {
-                eq[2 * threadIdx.x + 1] = hi;
-                eq[2 * threadIdx.x] = fq_sub(v, hi);
-            }
-            __syncthreads();
-        }
-    }
-    if ((int)threadIdx.x < (1 << m)) {
-        u32 l28[10];
-        fq28_unpack(eq[threadIdx.x], l28);
-#pragma unroll
-        for (int j = 0; j < 10; ++j) wl[threadIdx.x * 10 + j] = l28[j];
-    }
+    eq_weights28_block(ch, m, wl);
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
