@@ -277,7 +277,7 @@ int zk_ctx_set_tail_fold(zk_ctx *ctx, int max_log_table, int out_below_log);
  * evaluation triple per pass).  Proof bytes do not depend on it. */
 int zk_ctx_set_deg2_rounds_per_pass(zk_ctx *ctx, int rounds);
 /* Nine-sum sweeps over tables of at least 2^from_log quarter-entries (a quarter of the entries per table) accumulate
- * their products unreduced with one reduction per lane (default 20; negative = never).  Proof bytes do not depend on it. */
+ * their products unreduced with one reduction per lane (default 18; negative = never).  Proof bytes do not depend on it. */
 int zk_ctx_set_deg2_lazy_sums(zk_ctx *ctx, int from_log);
 enum { ZK_K_BLOCK_SUMS = 0, ZK_K_MULTIFOLD = 1, ZK_K_FOLD = 2, ZK_K_EVAL3 = 3, ZK_K_FOLD4_EVAL3 = 4, ZK_K_SUM9 = 5, ZK_K_FOLD2X4_SUM9 = 6, ZK_K_MULTIFOLD_WIDE = 7, ZK_K_MULTIFOLD_TAIL = 8,
        ZK_K_COUNT = 10 };

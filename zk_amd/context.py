@@ -52,7 +52,7 @@ class Context:
         """Degree-2 prover schedule: 2 rounds per device pass (default) or 1.  Proof bytes do not depend on it."""
         check(lib().zk_ctx_set_deg2_rounds_per_pass(self.h, rounds))
 
-    def set_deg2_lazy_sums(self, from_log: int = 20):
+    def set_deg2_lazy_sums(self, from_log: int = 18):
         """Degree-2 prover: nine-sum sweeps over >= 2^from_log quarter-entries use unreduced accumulation (negative: never)."""
         check(lib().zk_ctx_set_deg2_lazy_sums(self.h, from_log))
 

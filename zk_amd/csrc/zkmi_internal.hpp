@@ -71,7 +71,7 @@ struct zk_ctx {
     int wide_min_log_out = 16;   // ... taken while its output keeps at least 2^wide_min_log_out entries
     bool double_buffer = false;  // register double-buffering in k_multifold (tree variant)
     bool lazy = true;            // inner-product form with one reduction per output (k_multifold_lazy)
-    int deg2_lazy_from_log = 20; // nine-sum sweeps over tables of >= 2^k quarter-entries accumulate unreduced (k_sum9_lazy); < 0: never
+    int deg2_lazy_from_log = 18; // nine-sum sweeps over tables of >= 2^k quarter-entries accumulate unreduced (k_sum9_lazy); < 0: never
     uint64_t two24[4];           // 2^24 in Montgomery form (radix-2^28 reductions divide by 2^280, not 2^256)
     bool deg2_pairs = true;      // degree-2 prover: two rounds per device pass (k_sum9 / k_fold2x4_sum9)
     int lazy_group = 4;          // elements per register load buffer in k_multifold_lazy (2 or 4)
