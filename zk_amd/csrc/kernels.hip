@@ -71,6 +71,64 @@ __global__ void __launch_bounds__(kThreads) k_block_sums(const fq* __restrict__ 
     block_sum_store<1>(acc, partials);
 }
 
+// The same sums with the table streamed by LDS-DMA (global_load_lds_dwordx4: no VGPR destination) instead of register
+// loads: MI355X_MICROARCH.md measures 6.4 - 6.8 TB/s for LDS-DMA streams against 6.0 - 6.1 for register sweeps.  Every
+// wave runs its own ring of D rows (a row = 64 entries = 2 KiB = two DMA instructions, lane l reading entry l back
+// from LDS), D - 1 rows in flight behind a counted vmcnt; no barrier in the loop (waves share nothing) and `ring` is
+// the kernel's only __shared__ object (the final reduction reuses it).  Lb must be a multiple of 64.
+template <int D, int AUX>
+__global__ void __launch_bounds__(kThreads) k_block_sums_dma(const fq* __restrict__ T, size_t L, int log_ob, fq* __restrict__ partials) {
+    __shared__ u32x4 ring[kThreads / 64][D][128];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned gpb = gridDim.x >> log_ob;
+    const unsigned c = blockIdx.x / gpb, wl = blockIdx.x % gpb;
+    const size_t Lb = L >> log_ob;
+    const fq* __restrict__ base = T + (size_t)c * Lb;
+    const size_t nrows = Lb >> 6, wstride = (size_t)gpb * (kThreads / 64);
+    auto issue = [&](size_t r, int slot) {
+        const u32x4* src = reinterpret_cast<const u32x4*>(base + (r << 6)) + lane;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)&ring[wave][slot][0], 16, 0, AUX);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 64),
+                                         (__attribute__((address_space(3))) void*)&ring[wave][slot][64], 16, 0, AUX);
+    };
+    const size_t row0 = (size_t)wl * (kThreads / 64) + wave;
+    size_t r_issue = row0;
+    int inflight = 0;
+#pragma unroll
+    for (int sl = 0; sl < D; ++sl)
+        if (r_issue < nrows) { issue(r_issue, sl); r_issue += wstride; ++inflight; }
+    int slot = 0;
+    fq acc = fq_zero();
+    for (size_t r = row0; r < nrows; r += wstride) {
+        // the oldest outstanding row sits in `slot`; leave the D - 1 younger ones in flight (drain only near the end)
+        if (inflight == D) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (D - 1)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const u32x4 lo = ring[wave][slot][2 * lane], hi = ring[wave][slot][2 * lane + 1];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the entry is in registers before its slot is refilled
+        --inflight;
+        if (r_issue < nrows) { issue(r_issue, slot); r_issue += wstride; ++inflight; }
+        fq x;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { x.v[w] = lo[w]; x.v[4 + w] = hi[w]; }
+        acc = fq_add(acc, x);
+        slot = slot + 1 == D ? 0 : slot + 1;
+    }
+    // block sum through the ring's memory (every DMA has landed: the loop ends on vmcnt(0))
+    const fq wsum = fq_wave_sum(acc);
+    __syncthreads();
+    fq* red = reinterpret_cast<fq*>(&ring[0][0][0]);
+    if (lane == 0) red[wave] = wsum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        fq t = red[0];
+#pragma unroll
+        for (int w = 1; w < kThreads / 64; ++w) t = fq_add(t, red[w]);
+        fq_store(&partials[blockIdx.x], t);
+    }
+}
+
 template <int M> struct Chal { fq r[M]; };
 
 template <int M>
@@ -890,6 +948,15 @@ static inline int grid_blocks(size_t Lb, int log_ob) {
     return (int)(per << log_ob);
 }
 int launch_block_sums(const void* T, size_t L, int log_ob, void* partials, void* out, hipStream_t st) {
+    const size_t Lb0 = L >> log_ob;
+    // large tables: LDS-DMA stream with the nt policy, 6.7 vs 6.1 TB/s at 2^28 entries; it wins from 2^27 entries
+    // (0.667 vs 0.722 ms), ties at 2^25 and loses at 2^26 and below (its 64 KiB of LDS per workgroup cap the waves per CU)
+    if (Lb0 % 64 == 0 && L >= ((size_t)1 << 27)) {
+        int g = grid_blocks(Lb0 / 64, log_ob);
+        hipLaunchKernelGGL((k_block_sums_dma<8, 2>), dim3(g), dim3(kThreads), 0, st, (const fq*)T, L, log_ob, (fq*)partials);
+        hipLaunchKernelGGL(k_reduce_groups, dim3(1 << log_ob), dim3(kThreads), 0, st, (const fq*)partials, g >> log_ob, (fq*)out);
+        return g;
+    }
     int g = grid_blocks(L >> log_ob, log_ob);
     hipLaunchKernelGGL(k_block_sums, dim3(g), dim3(kThreads), 0, st, (const fq*)T, L, log_ob, (fq*)partials);
     hipLaunchKernelGGL(k_reduce_groups, dim3(1 << log_ob), dim3(kThreads), 0, st, (const fq*)partials, g >> log_ob, (fq*)out);
