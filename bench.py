@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--fold-batch", type=int, default=0, help="rounds bound per device pass (0 = library default)")
     ap.add_argument("--wide-batch", type=int, default=-1, help="rounds bound by a pass over a large table (5..8, 0 = off, -1 = library default 8)")
     ap.add_argument("--wide-min-log-out", type=int, default=16, help="wide passes are taken while the folded table keeps >= 2^k entries")
-    ap.add_argument("--wide-lds-below", type=int, default=19, help="wide passes with < 2^k outputs make their weights per workgroup in LDS")
+    ap.add_argument("--wide-lds-below", type=int, default=17, help="wide passes with < 2^k outputs make their weights per workgroup in LDS")
     ap.add_argument("--tail-max-log", type=int, default=-1, help="tables of <= 2^k entries bind eight rounds per pass (0 = off, -1 = library default 16)")
     ap.add_argument("--tail-out-below", type=int, default=13, help="passes with < 2^k outputs use one wave per output")
     ap.add_argument("--fold-variant", type=int, default=0, help="0 eq-weight inner product, 1 tree, 2 tree+double buffer")

@@ -265,7 +265,7 @@ int zk_ctx_set_fold_batch(zk_ctx *ctx, int rounds_per_pass, int variant);
 /* Passes over a LARGE table bind up to `rounds` variables at once (5..8, default 8; 0 = off): as many as leave
  * the folded table at least 2^min_log_out entries (default 16), when that is `rounds` itself or at least two more
  * than the default batch.  At 2^8 read streams per store stream the pass runs at the read-only HBM rate
- * (fold-pass ceiling).  lds_weights_below_log (default 19; 0 = never, 64 = always): wide passes with
+ * (fold-pass ceiling).  lds_weights_below_log (default 17; 0 = never, 64 = always): wide passes with
  * fewer than 2^k outputs derive their weights per workgroup in LDS (one launch, latency matters), larger ones
  * read them from a small device buffer as scalar loads (4 waves per SIMD).  Proof bytes do not depend on any of it. */
 int zk_ctx_set_wide_fold(zk_ctx *ctx, int rounds, int min_log_out, int lds_weights_below_log);

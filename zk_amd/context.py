@@ -37,7 +37,7 @@ class Context:
         2 = tree + double buffering, 3..6 = load-pipelining variants of 0."""
         check(lib().zk_ctx_set_fold_batch(self.h, rounds_per_pass, variant))
 
-    def set_wide_fold(self, rounds: int = 8, min_log_out: int = 16, lds_weights_below_log: int = 19):
+    def set_wide_fold(self, rounds: int = 8, min_log_out: int = 16, lds_weights_below_log: int = 17):
         """Passes over a large table bind up to `rounds` (5..8; 0 = off) variables while the folded table keeps at least
         2^min_log_out entries; wide passes with fewer than 2^lds_weights_below_log outputs make their weights per
         workgroup in LDS, larger ones read them as scalar loads.  Proof bytes do not depend on it."""

@@ -389,6 +389,86 @@ __device__ __forceinline__ void eq_weights28_block(const ChalWide& ch, int m, u3
 }
 __global__ void __launch_bounds__(kThreads) k_eq_weights28(ChalWide ch, int m, u32* __restrict__ wout) { eq_weights28_block(ch, m, wout); }
 
+// The wide pass with its 2^m read streams fed by LDS-DMA (nt policy), as k_block_sums_dma: a wave owns groups of 64
+// consecutive outputs; the 2^m source rows of a group (row b = 64 entries at b * Lout + j, 2 KiB, two DMA instructions)
+// run through the wave's ring of D slots, D - 1 rows in flight behind a counted vmcnt, the stream continuing across
+// the wave's groups.  Lane l reads entry l of the row back from LDS and multiplies it into ITS output's unreduced
+// accumulator with weight b (scalar loads).  No load buffers in registers, no barrier in the loop; the store of a
+// finished group is followed by one vmcnt(0) (stores share the counter) -- once per 2^m rows.  `ring` is the kernel's
+// only __shared__ object.  Lb (outputs per block) must be a multiple of 64.
+template <bool BIG, int D>
+__global__ void __launch_bounds__(kThreads) k_multifold_wide_dma(const fq* __restrict__ src, fq* __restrict__ dst, size_t Lout,
+                                                                  const u32* __restrict__ wts, int m, int log_ob, fq* __restrict__ partials) {
+    __shared__ u32x4 ring[kThreads / 64][D][128];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned gpb = gridDim.x >> log_ob;
+    const unsigned c = blockIdx.x / gpb, wi = blockIdx.x % gpb;
+    const size_t Lb = Lout >> log_ob, j0 = (size_t)c * Lb;
+    const unsigned ngroups = (unsigned)(Lb >> 6), gstride = gpb * (kThreads / 64);
+    const unsigned nb = 1u << m;
+    auto issue = [&](unsigned group, unsigned b, int slot) {
+        const u32x4* p = reinterpret_cast<const u32x4*>(src + (size_t)b * Lout + j0 + ((size_t)group << 6)) + lane;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
+                                         (__attribute__((address_space(3))) void*)&ring[wave][slot][0], 16, 0, 2);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p + 64),
+                                         (__attribute__((address_space(3))) void*)&ring[wave][slot][64], 16, 0, 2);
+    };
+    const unsigned g0 = wi * (kThreads / 64) + wave;
+    unsigned ig = g0, ib = 0; // next row to issue
+    int inflight = 0;
+#pragma unroll
+    for (int sl = 0; sl < D; ++sl)
+        if (ig < ngroups) {
+            issue(ig, ib, sl);
+            ++inflight;
+            if (++ib == nb) { ib = 0; ig += gstride; }
+        }
+    int slot = 0;
+    fq run = fq_zero();
+    for (unsigned g = g0; g < ngroups; g += gstride) {
+        u64 acc[20];
+#pragma unroll
+        for (int k = 0; k < 20; ++k) acc[k] = 0;
+        const u32* __restrict__ w = wts; // wave-uniform: scalar loads
+        for (unsigned b = 0; b < nb; ++b) {
+            if (inflight == D) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (D - 1)) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const u32x4 lo = ring[wave][slot][2 * lane], hi = ring[wave][slot][2 * lane + 1];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // in registers before the slot is refilled
+            --inflight;
+            if (ig < ngroups) {
+                issue(ig, ib, slot);
+                ++inflight;
+                if (++ib == nb) { ib = 0; ig += gstride; }
+            }
+            fq x;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { x.v[k] = lo[k]; x.v[4 + k] = hi[k]; }
+            fq28_mac(acc, x, w);
+            if ((b & 15) == 15) fq28_carry(acc); // every 16 products
+            w += 10;
+            slot = slot + 1 == D ? 0 : slot + 1;
+        }
+        const fq o = fq28_redc(acc);
+        fq* out = dst + j0 + ((size_t)g << 6) + lane;
+        if (BIG) fq_store_stream(out, o); else fq_store(out, o);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // stores count in vmcnt too: start the next group's counting clean
+        run = fq_add(run, o);
+    }
+    const fq wsum = fq_wave_sum(run);
+    __syncthreads();
+    fq* red = reinterpret_cast<fq*>(&ring[0][0][0]);
+    if (lane == 0) red[wave] = wsum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        fq t = red[0];
+#pragma unroll
+        for (int k = 1; k < kThreads / 64; ++k) t = fq_add(t, red[k]);
+        fq_store(&partials[blockIdx.x], t);
+    }
+}
+
 template <bool BIG> // BIG: the output is beyond the caches: streaming stores
 __global__ void __launch_bounds__(kThreads) k_multifold_wide(const fq* __restrict__ src, fq* __restrict__ dst, size_t Lout,
                                                               const u32* __restrict__ wts, int m, int log_ob, fq* __restrict__ partials) {
@@ -1048,6 +1128,21 @@ int launch_multifold_wide(int m, const void* src, void* dst, size_t Lout, const 
         return g;
     }
     hipLaunchKernelGGL(k_eq_weights28, dim3(1), dim3(kThreads), 0, st, ch, m, (u32*)wbuf);
+    if (((Lout >> log_ob) % 64) == 0) { // LDS-DMA streams (every large pass): 5.9 vs 5.5 TB/s at 2^28 entries; ring depth 3, 4, 6 alike
+        // one group of 64 outputs per wave-step; at most 1024 workgroups = 4 per CU (at 2^28 entries: exactly 4 groups per wave)
+        size_t per = ((Lout >> log_ob) / 64 + 3) / 4, cap = (size_t)1024 >> log_ob;
+        if (per > cap) per = cap;
+        if (per < 1) per = 1;
+        const int g = (int)(per << log_ob);
+        if (Lout >= ((size_t)1 << 22))
+            hipLaunchKernelGGL((k_multifold_wide_dma<true, 4>), dim3(g), dim3(kThreads), 0, st, (const fq*)src, (fq*)dst, Lout, (const u32*)wbuf,
+                               m, log_ob, (fq*)partials);
+        else
+            hipLaunchKernelGGL((k_multifold_wide_dma<false, 4>), dim3(g), dim3(kThreads), 0, st, (const fq*)src, (fq*)dst, Lout, (const u32*)wbuf,
+                               m, log_ob, (fq*)partials);
+        hipLaunchKernelGGL(k_reduce_groups, dim3(1 << log_ob), dim3(kThreads), 0, st, (const fq*)partials, g >> log_ob, (fq*)out);
+        return g;
+    }
     int g = grid_blocks_wide(Lout >> log_ob, log_ob);
     if (Lout >= ((size_t)1 << 22))
         hipLaunchKernelGGL(k_multifold_wide<true>, dim3(g), dim3(kThreads), 0, st, (const fq*)src, (fq*)dst, Lout, (const u32*)wbuf, m, log_ob,
