@@ -48,7 +48,8 @@ static constexpr int kMaxBlocks9 = 1024;
 void launch_sum9(const void* const t[4], size_t q, const uint64_t fix24[4], int lazy_from_log, void* partials, void* out, hipStream_t st);
 // bind the two top variables of four tables of 4*outlen entries (w28: the 4 eq weights as for launch_multifold_lazy)
 // into d[] (outlen entries each)
-void launch_fold2_tables(const void* const s[4], void* const d[4], size_t outlen, const uint32_t* w28, hipStream_t st);
+// wbuf (device, >= 40 u32) and partials (>= 1024 elements) are scratch for the large-table form; either may be null (then never used)
+void launch_fold2_tables(const void* const s[4], void* const d[4], size_t outlen, const uint32_t* w28, void* wbuf, void* partials, hipStream_t st);
 // out[k*n + i] = t[k][i], k < 4, i < n
 void launch_gather4(const void* const t[4], size_t n, void* out, hipStream_t st);
 void launch_from_le32(const void* in, void* out, size_t n, hipStream_t st);

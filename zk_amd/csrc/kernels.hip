@@ -858,9 +858,9 @@ __global__ void __launch_bounds__(576) k_sum9_lazy(Tab4 T, size_t q, fq fix24, f
             const fq* src = ((w & 4) ? G : F) + (size_t)(w & 3) * q + j;
             u32x4* buf = &sh[t % 3][w][0][0];
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)reinterpret_cast<const u32x4*>(src),
-                                             (__attribute__((address_space(3))) void*)buf, 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)buf, 16, 0, 2);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(reinterpret_cast<const u32x4*>(src) + 1),
-                                             (__attribute__((address_space(3))) void*)(buf + 64), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(buf + 64), 16, 0, 2);
         }
     };
     if (nt > 0) stage(0);
@@ -1223,13 +1223,34 @@ void launch_gather4(const void* const t[4], size_t n, void* out, hipStream_t st)
     for (int k = 0; k < 4; ++k) T.t[k] = (const fq*)t[k];
     hipLaunchKernelGGL(k_gather4, dim3((unsigned)((4 * n + kThreads - 1) / kThreads)), dim3(kThreads), 0, st, T, n, (fq*)out);
 }
-void launch_fold2_tables(const void* const s[4], void* const d[4], size_t outlen, const uint32_t* w28, hipStream_t st) {
+// the four weights of a two-variable fold into device memory (for the LDS-DMA fold, which takes them as scalar loads)
+__global__ void __launch_bounds__(64) k_store_w28x4(W28<2> W, u32* __restrict__ out) {
+    if (threadIdx.x < 40) out[threadIdx.x] = W.w[threadIdx.x / 10][threadIdx.x % 10];
+}
+void launch_fold2_tables(const void* const s[4], void* const d[4], size_t outlen, const uint32_t* w28, void* wbuf, void* partials, hipStream_t st) {
     Tab4 S;
     Tab4w D;
     for (int k = 0; k < 4; ++k) { S.t[k] = (const fq*)s[k]; D.t[k] = (fq*)d[k]; }
     W28<2> W;
     for (int b = 0; b < 4; ++b)
         for (int j = 0; j < 10; ++j) W.w[b][j] = w28[b * 10 + j];
+    if (wbuf && partials && outlen % 64 == 0 && outlen >= ((size_t)1 << 22)) {
+        // the largest tables: each table is one m = 2 pass of the LDS-DMA fold (its block sum is not used).  The pass stays
+        // bound by its store stream (1 store per 4 reads): 4.67 -> 4.85 TB/s only, and slower than the lane-per-output
+        // kernel below 2^22 outputs per table
+        hipLaunchKernelGGL(k_store_w28x4, dim3(1), dim3(64), 0, st, W, (u32*)wbuf);
+        size_t per = (outlen / 64 + 3) / 4;
+        if (per > 1024) per = 1024;
+        for (int k = 0; k < 4; ++k) {
+            if (outlen >= ((size_t)1 << 22))
+                hipLaunchKernelGGL((k_multifold_wide_dma<true, 4>), dim3((unsigned)per), dim3(kThreads), 0, st, S.t[k], D.t[k], outlen, (const u32*)wbuf, 2,
+                                   0, (fq*)partials);
+            else
+                hipLaunchKernelGGL((k_multifold_wide_dma<false, 4>), dim3((unsigned)per), dim3(kThreads), 0, st, S.t[k], D.t[k], outlen,
+                                   (const u32*)wbuf, 2, 0, (fq*)partials);
+        }
+        return;
+    }
     size_t gx = (outlen + kThreads - 1) / kThreads;
     if (gx < 1) gx = 1;
     if (gx > (size_t)kMaxBlocks) gx = kMaxBlocks;

@@ -743,7 +743,7 @@ static int prove_sum2x2_pairs(zk_ctx* c, const void* const tables[4], size_t len
         eq_weights28(rs, 2, w28);
         {
             ProfScope ps(c, ZK_K_FOLD2X4_SUM9, (uint64_t)curlen * 32 * 4 + (uint64_t)outlen * 32 * 4);
-            zkk::launch_fold2_tables(cur, dst, outlen, w28, c->stream);
+            zkk::launch_fold2_tables(cur, dst, outlen, w28, c->wide_w, c->partials, c->stream);
         }
         if (outlen > kHostTail) {
             ProfScope ps(c, ZK_K_SUM9, (uint64_t)outlen * 32 * 4);
@@ -917,7 +917,7 @@ int zk_shard4_fold2(zk_shard4* s, const uint64_t r2[8], void* sums_dev_out) {
     eq_weights28(r2, 2, w28);
     {
         ProfScope ps(c, ZK_K_FOLD2X4_SUM9, (uint64_t)s->len * 32 * 4 + (uint64_t)outlen * 32 * 4);
-        zkk::launch_fold2_tables(s->cur, dst, outlen, w28, c->stream);
+        zkk::launch_fold2_tables(s->cur, dst, outlen, w28, c->wide_w, c->partials, c->stream);
     }
     if (sums_dev_out && outlen >= 4) {
         ProfScope ps(c, ZK_K_SUM9, (uint64_t)outlen * 32 * 4);
