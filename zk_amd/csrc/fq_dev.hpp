@@ -162,13 +162,21 @@ __device__ __forceinline__ fq fq_from_mont(const fq& a) {
 // A weighted sum  sum_b a_b * w_b  (the m-variable fold written as one inner product with the
 // eq weights) needs ONE Montgomery reduction, not one per product, if the 512-bit products are
 // accumulated unreduced.  With 32-bit limbs every v_mad_u64_u32 needs its carry-out caught
-// (2 VALU ops per limb product, fq_mul_asm.inc); with 10 limbs of 28 bits a limb product is
-// < 2^56, so a u64 column takes up to 2^8 of them with no carry handling at all: 1 VALU op
+// (2 VALU ops per limb product, fq_mul_asm.inc); with 28-bit limbs a limb product is < 2^56 and a
+// u64 column takes many of them with no carry handling at all: 1 VALU op
 // (v_mad_u64_u32 acc, a, w, acc) per limb product, written in plain C++.
 // The reduction is Montgomery in radix 2^28 over 10 limbs, i.e. it divides by 2^280: the host
 // supplies the weights as w * 2^280 / 2^256 so the result is again in R = 2^256 Montgomery form.
+//
+// Limb count.  Bits 224..255 are word 7 as it stands, and for a canonical element (< p < 2^254) that word is below
+// 0x30644e73 < 0.76 * 2^30: it is used as ONE top limb, so a product is 9 x 9 = 81 limb products, not the 100 of a
+// uniform 10-limb split (the limb products are what the fold passes spend their VALU time on).  Column bound: the
+// widest column (k = 8) takes two terms with a top limb (< 2 * 0.76 * 2^58) and seven plain ones (< 7 * 2^56), i.e.
+// < 13.1 * 2^56 per product, so 16 products stay below 210 * 2^56 < 2^64 -- the carry cadence the callers use.
+// Both operands must be canonical; stored weights keep the 10 x 28-bit layout (limbs 8 and 9 are joined on use).
 #define FQ28_MASK 0x0fffffffu
 
+// 8 limbs of 28 bits and the top word whole; l[9] is unused (zero) -- the array keeps the stored 10-word layout
 __device__ __forceinline__ void fq28_unpack(const fq& a, u32 (&l)[10]) {
     l[0] = a.v[0] & FQ28_MASK;
     l[1] = ((a.v[0] >> 28) | (a.v[1] << 4)) & FQ28_MASK;
@@ -178,33 +186,34 @@ __device__ __forceinline__ void fq28_unpack(const fq& a, u32 (&l)[10]) {
     l[5] = ((a.v[4] >> 12) | (a.v[5] << 20)) & FQ28_MASK;
     l[6] = ((a.v[5] >> 8) | (a.v[6] << 24)) & FQ28_MASK;
     l[7] = a.v[6] >> 4;
-    l[8] = a.v[7] & FQ28_MASK;
-    l[9] = a.v[7] >> 28;
+    l[8] = a.v[7];
+    l[9] = 0;
+}
+// the uniform 10-limb split, for operands that are NOT canonical (plain sums of entries, up to 2^256 - 1)
+__device__ __forceinline__ void fq28_unpack10(const fq& a, u32 (&l)[10]) {
+    fq28_unpack(a, l);
+    l[9] = l[8] >> 28;
+    l[8] &= FQ28_MASK;
 }
 
-// acc (20 u64 columns, weight 2^(28k)) += a * w ; w: 10 wave-uniform 28-bit limbs
+// acc (20 u64 columns, weight 2^(28k)) += a * w ; a already unpacked, w: stored weight (10 x 28-bit limbs)
+__device__ __forceinline__ void fq28_mac_limbs(u64 (&acc)[20], const u32 (&l)[10], const u32* __restrict__ w) {
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+        const u32 wj = j < 8 ? w[j] : (w[8] | (w[9] << 28));
+#pragma unroll
+        for (int i = 0; i < 9; ++i) acc[i + j] += (u64)l[i] * wj;
+    }
+}
+// the same from the packed element
 __device__ __forceinline__ void fq28_mac(u64 (&acc)[20], const fq& a, const u32* __restrict__ w) {
     u32 l[10];
     fq28_unpack(a, l);
-#pragma unroll
-    for (int j = 0; j < 10; ++j) {
-        const u32 wj = w[j];
-#pragma unroll
-        for (int i = 0; i < 10; ++i) acc[i + j] += (u64)l[i] * wj;
-    }
+    fq28_mac_limbs(acc, l, w);
 }
 
-// the same with the element already unpacked
-__device__ __forceinline__ void fq28_mac_limbs(u64 (&acc)[20], const u32 (&l)[10], const u32* __restrict__ w) {
-#pragma unroll
-    for (int j = 0; j < 10; ++j) {
-        const u32 wj = w[j];
-#pragma unroll
-        for (int i = 0; i < 10; ++i) acc[i + j] += (u64)l[i] * wj;
-    }
-}
-
-// acc += a * b, both operands already unpacked (variable x variable: the degree-2 sums)
+// acc += a * b, both operands in the uniform 10-limb split (variable x variable, operands up to 2^256 - 1: the
+// degree-2 sums over plain sums of entries)
 __device__ __forceinline__ void fq28_mac_vv(u64 (&acc)[20], const u32 (&a)[10], const u32 (&b)[10]) {
 #pragma unroll
     for (int j = 0; j < 10; ++j)
