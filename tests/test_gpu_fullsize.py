@@ -168,3 +168,36 @@ def test_sum2x2_2pow24_both_nine_sum_kernels_agree():
         del tabs, f
         ctx.close()
     assert np.array_equal(proofs[0][0], proofs[1][0]) and np.array_equal(proofs[0][1], proofs[1][1])
+
+
+def test_constant_tables_of_p_minus_1_worst_case_limbs():
+    """Every stored word at its maximum for a canonical element (p - 1: top word 0x30644e72): the unreduced column
+    sums of the fold passes (16 products between carries) and of the nine-sum sweep (8 products of plain sums of four
+    entries, i.e. operands of 4p - 4) are at the bound fq_dev.hpp derives.  A constant table folds to itself at
+    any challenge, so the proof is known in closed form; the two nine-sum kernels must also agree."""
+    pm1 = np.array([[(P - 1) >> (64 * k) & 0xFFFFFFFFFFFFFFFF for k in range(4)]], dtype=np.uint64)  # the STORED words
+    n = 1 << 24
+    ctx = zk_amd.Context(0)
+    poly = MLE(np.ascontiguousarray(np.broadcast_to(pm1, (n, 4))), ctx=ctx)
+    tr = zk_amd.Transcript()
+    tr.append(b"const")
+    claim, coeffs, ch = zk_amd.SumcheckProver.generate_round_polys(poly, tr)
+    tv = zk_amd.Transcript()
+    tv.append(b"const")
+    ok, final, ch2 = zk_amd.SumcheckVerifier.partial_verify(zk_amd.SumCheckProof(claim, coeffs), tv)
+    assert ok and np.array_equal(ch, ch2)
+    assert np.array_equal(np.asarray(final).reshape(-1), pm1.reshape(-1))          # folds to itself
+    val = poly.evaluate([c for c in ch]).get_evaluation_points()
+    assert np.array_equal(val[0], pm1.reshape(-1))
+    del poly
+    proofs = []
+    m = 1 << 23
+    for lazy_from in (18, -1):
+        ctx.set_deg2_lazy_sums(lazy_from)
+        tabs = [MLE(np.ascontiguousarray(np.broadcast_to(pm1, (m, 4))), ctx=ctx) for _ in range(4)]
+        f = zk_amd.SumPolynomial([zk_amd.ProductPolynomial(tabs[:2]), zk_amd.ProductPolynomial(tabs[2:])])
+        proof, pts = zk_amd.SumcheckProver.generate_proof_for_partial_verify(O.fq1(0), f, zk_amd.Transcript())
+        proofs.append((proof.round_polys.copy(), pts.copy()))
+        del tabs, f
+    assert np.array_equal(proofs[0][0], proofs[1][0]) and np.array_equal(proofs[0][1], proofs[1][1])
+    ctx.close()

@@ -189,13 +189,6 @@ __device__ __forceinline__ void fq28_unpack(const fq& a, u32 (&l)[10]) {
     l[8] = a.v[7];
     l[9] = 0;
 }
-// the uniform 10-limb split, for operands that are NOT canonical (plain sums of entries, up to 2^256 - 1)
-__device__ __forceinline__ void fq28_unpack10(const fq& a, u32 (&l)[10]) {
-    fq28_unpack(a, l);
-    l[9] = l[8] >> 28;
-    l[8] &= FQ28_MASK;
-}
-
 // acc (20 u64 columns, weight 2^(28k)) += a * w ; a already unpacked, w: stored weight (10 x 28-bit limbs)
 __device__ __forceinline__ void fq28_mac_limbs(u64 (&acc)[20], const u32 (&l)[10], const u32* __restrict__ w) {
 #pragma unroll
@@ -212,15 +205,22 @@ __device__ __forceinline__ void fq28_mac(u64 (&acc)[20], const fq& a, const u32*
     fq28_mac_limbs(acc, l, w);
 }
 
-// acc += a * b, both operands in the uniform 10-limb split (variable x variable, operands up to 2^256 - 1: the
-// degree-2 sums over plain sums of entries)
+// acc += a * b, both operands unpacked by fq28_unpack (variable x variable: the degree-2 sums).  The operands may be
+// plain sums of up to four canonical entries (< 4p < 2^256, top word anything): the one product of the two top words
+// could pass 2^63, so it is split over columns 16 and 17 -- 82 limb products.  Column bound: k = 8 takes two terms
+// with a top word (< 2 * 2^28 * 0.76 * 2^32 = 24.2 * 2^56) and seven plain ones, < 31.2 * 2^56 per product:
+// carry at least every 8 products.
 __device__ __forceinline__ void fq28_mac_vv(u64 (&acc)[20], const u32 (&a)[10], const u32 (&b)[10]) {
 #pragma unroll
-    for (int j = 0; j < 10; ++j)
+    for (int j = 0; j < 9; ++j)
 #pragma unroll
-        for (int i = 0; i < 10; ++i) acc[i + j] += (u64)a[i] * b[j];
+        for (int i = 0; i < 9; ++i)
+            if (i + j < 16) acc[i + j] += (u64)a[i] * b[j];
+    acc[16] += (u64)a[8] * (b[8] & FQ28_MASK);
+    acc[17] += (u64)a[8] * (b[8] >> 28);
 }
 // every column back below 2^28 (the top one keeps the overflow): call at least every 16 accumulated products
+// (every 8 with fq28_mac_vv)
 __device__ __forceinline__ void fq28_carry(u64 (&acc)[20]) {
 #pragma unroll
     for (int k = 0; k < 19; ++k) {

@@ -886,10 +886,10 @@ __global__ void __launch_bounds__(576) k_sum9_lazy(Tab4 T, size_t q, fq fix24, f
             return x;
         };
         u32 lf[10], lg[10];
-        fq28_unpack10(opnd(0), lf);
-        fq28_unpack10(opnd(1), lg);
+        fq28_unpack(opnd(0), lf);
+        fq28_unpack(opnd(1), lg);
         fq28_mac_vv(acc, lf, lg);
-        if (++since == 16) {
+        if (++since == 8) { // fq28_mac_vv's bound for operands up to 4p
             since = 0;
             fq28_carry(acc);
         }
