@@ -269,11 +269,11 @@ def bench_single(args, ctx, zk_amd, np):
     ms = ctx.bench_modmul(blocks, iters)
     modmul_per_s = blocks * 256 * iters / (ms * 1e-3)
     alu = {"modmul_per_s": modmul_per_s, "note": "peak = dependent fq_mul chain, 2048x256 lanes (k_modmul_probe)"}
-    if "multifold_wide" in kernels:  # the wide fold pass: one 10x10-limb inner product (100 v_mad_u64_u32) per input entry
+    if "multifold_wide" in kernels:  # the wide fold pass: one 9x9-limb inner product (81 v_mad_u64_u32) per input entry
         k = kernels["multifold_wide"]
         entries = k["alg_bytes_per_launch"] / 32.0 * 256 / 257
-        alu["fold_pass_limb_mads_per_s"] = 100 * entries / (k["avg_ms"] * 1e-3)
-        alu["fold_pass_products_equiv_frac"] = (entries / (k["avg_ms"] * 1e-3)) / modmul_per_s  # products of 100 of fq_mul's ~270 ops: memory-bound by design
+        alu["fold_pass_limb_mads_per_s"] = 81 * entries / (k["avg_ms"] * 1e-3)
+        alu["fold_pass_products_equiv_frac"] = (entries / (k["avg_ms"] * 1e-3)) / modmul_per_s  # products of 81 of fq_mul's ~270 ops: memory-bound by design
     if "sum9" in kernels:            # nine-sum sweeps: 18 field products per quarter-index (16 entries of 32 B)
         k = kernels["sum9"]
         prod = 18 * k["alg_bytes_per_launch"] * k["launches"] / 512.0
