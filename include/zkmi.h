@@ -11,7 +11,9 @@
  *  - Field elements cross the boundary as 4 x u64 little-endian limbs of a*R mod p
  *    (R = 2^256, fully reduced) -- ark-ff's in-memory form of `Fp256<MontBackend>` --
  *    unless a name says le32 (canonical value, 32 little-endian bytes =
- *    `into_bigint().to_bytes_le()`).
+ *    `into_bigint().to_bytes_le()`).  Limbs that are not fully reduced (value >= p) are outside the
+ *    contract, as they are for ark-ff: the kernels' unreduced accumulations size their carry cadence for
+ *    reduced operands (zk_amd/csrc/fq_dev.hpp), and results for other inputs are unspecified.
  *  - Every function returns a zk_status; where the reference panics, a non-zero code is
  *    returned instead (the Rust shim turns it back into panic!).  Verifiers' `bool`
  *    results come back through an int* out-parameter.
