@@ -844,7 +844,12 @@ __global__ void __launch_bounds__(576) k_sum9_lazy(Tab4 T, size_t q, fq fix24, f
     __shared__ u32x4 sh[3][8][2][64];
     const int term = blockIdx.y, lane = threadIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.y);
-    const int A = w % 3, B = w / 3; // 0, 1, 2 = '+'
+    // which of the nine products this wave forms.  The nine waves of a workgroup sit 3/2/2/2 on the four SIMDs (wave w on
+    // SIMD w % 4) and meet at a barrier every tile, and a product over '+' operands costs 1 or 3 extra 256-bit additions
+    // per factor: the SIMD with three waves (0, 4, 8) gets three of the plain products, the (+,+) product shares a SIMD
+    // with the fourth.  Nibble w of the constant = 3B + A.
+    const int role = (int)((0x375416280ull >> (4 * w)) & 15);
+    const int A = role % 3, B = role / 3; // 0, 1, 2 = '+'
     const fq* __restrict__ F = T.t[2 * term];
     const fq* __restrict__ G = T.t[2 * term + 1];
     u64 acc[20];
