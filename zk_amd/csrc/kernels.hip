@@ -818,7 +818,7 @@ __global__ void __launch_bounds__(kThreads) k_sum9(Tab4 T, size_t q, fq* __restr
 }
 
 // Large tables: the sums are bound by the 18 field products per quarter-index, not by HBM.  Here the products are
-// accumulated UNREDUCED in radix 2^28 (fq_dev.hpp) -- 100 v_mad_u64_u32 per product and one Montgomery reduction per
+// accumulated UNREDUCED in radix 2^28 (fq_dev.hpp) -- 82 v_mad_u64_u32 per product and one Montgomery reduction per
 // lane at the very end, instead of a full fq_mul (136 + carries) per product -- and the operands are formed with
 // plain 256-bit additions instead of modular differences: with '+' for "entry at 0 plus entry at 1" (= twice the value
 // at 1/2) the kernel sums  U[a][b] = sum_j F[a][b] G[a][b],  a, b in {0, 1, +}  (a on the top variable, b on the second),
