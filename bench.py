@@ -409,31 +409,6 @@ def bench_sharded(args, zk_amd, np, dist, rank, local_rank, world):
     }
 
 
-def splitmix64(x):
-    import numpy as np
-
-    with np.errstate(over="ignore"):
-        z = x + np.uint64(0x9E3779B97F4A7C15)
-        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
-        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
-        return z ^ (z >> np.uint64(31))
-
-
-def gkr_layers(depth: int, log_w: int, np):
-    """every layer W = 2^log_w gates; gate g reads left = 2g mod W,
-    right = (2g+1) mod W; op = Mul if splitmix64(seed, layer, g) & 1 else Add."""
-    W = 1 << log_w
-    g = np.arange(W, dtype=np.uint64)
-    layers = []
-    for layer in range(depth):
-        a = np.empty((W, 3), dtype=np.uint64)
-        a[:, 0] = (2 * g) % np.uint64(W)
-        a[:, 1] = (2 * g + np.uint64(1)) % np.uint64(W)
-        a[:, 2] = splitmix64(np.uint64(SEED) + np.uint64(layer) * np.uint64(1 << 32) + g) & np.uint64(1)
-        layers.append(a)
-    return layers
-
-
 def bench_gkr(args, ctx, zk_amd, np):
     """Full GKR prove (gkr/src/prover.rs:24-154) of a layered circuit: circuit evaluation, predicate
     folding from the gate lists and every layer's degree-2 sumcheck on the device."""
@@ -441,7 +416,9 @@ def bench_gkr(args, ctx, zk_amd, np):
 
     depth, k = args.gkr_depth, args.gkr_log_width
     t0 = time.perf_counter()
-    circuit = zk_amd.Circuit.from_arrays(gkr_layers(depth, k, np), ctx=ctx)
+    from zk_amd.synthetic import gkr_layers
+
+    circuit = zk_amd.Circuit.from_arrays(gkr_layers(depth, k), ctx=ctx)
     build_ms = (time.perf_counter() - t0) * 1e3
     inputs = zk_amd.MultiLinearPolynomial.generate(SEED, 1 << k, ctx=ctx)
 

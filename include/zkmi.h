@@ -281,6 +281,18 @@ int zk_ctx_set_deg2_rounds_per_pass(zk_ctx *ctx, int rounds);
 /* Nine-sum sweeps over tables of at least 2^from_log quarter-entries (a quarter of the entries per table) accumulate
  * their products unreduced with one reduction per lane (default 18; negative = never).  Proof bytes do not depend on it. */
 int zk_ctx_set_deg2_lazy_sums(zk_ctx *ctx, int from_log);
+/* Size thresholds (log2 of entries; 64 = never) of the LDS-DMA forms of the big passes, whose defaults are the measured
+ * break-even points: block sums stream through LDS-DMA rings from tables of 2^sums_from_log entries (default 27); wide
+ * fold passes use streaming stores from 2^wide_stream_from_log outputs (default 22); the degree-2 two-variable fold runs as
+ * m = 2 LDS-DMA passes from 2^fold2_from_log outputs per table (default 22).  The parity tests lower them so that the
+ * kernels the benchmark numbers come from run on oracle-sized tables.  Proof bytes do not depend on any of it. */
+int zk_ctx_set_dma_gates(zk_ctx *ctx, int sums_from_log, int wide_stream_from_log, int fold2_from_log);
+/* Which kernel forms the launches of the calling thread took since the last reset (bit mask, ZK_FORM_*): lets a test
+ * assert that the form it forced is the one that ran. */
+enum { ZK_FORM_SUMS_DMA = 1 << 0, ZK_FORM_SUMS_REG = 1 << 1, ZK_FORM_WIDE_DMA = 1 << 2, ZK_FORM_WIDE_DMA_STREAM = 1 << 3,
+       ZK_FORM_WIDE_REG = 1 << 4, ZK_FORM_WIDE_LDS = 1 << 5, ZK_FORM_COOP = 1 << 6, ZK_FORM_FOLD2_DMA = 1 << 7,
+       ZK_FORM_FOLD2_REG = 1 << 8, ZK_FORM_SUM9_LAZY = 1 << 9, ZK_FORM_SUM9 = 1 << 10, ZK_FORM_FOLD2_SUM9 = 1 << 11 };
+unsigned zk_ctx_forms_used(zk_ctx *ctx, int reset);
 enum { ZK_K_BLOCK_SUMS = 0, ZK_K_MULTIFOLD = 1, ZK_K_FOLD = 2, ZK_K_EVAL3 = 3, ZK_K_FOLD4_EVAL3 = 4, ZK_K_SUM9 = 5, ZK_K_FOLD2X4_SUM9 = 6, ZK_K_MULTIFOLD_WIDE = 7, ZK_K_MULTIFOLD_TAIL = 8,
        ZK_K_COUNT = 10 };
 /* per-kernel HIP-event timing of the launches made by the provers on this context */

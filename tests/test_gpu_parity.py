@@ -331,3 +331,102 @@ def test_sum2x2_both_schedules_give_the_oracle_proof(rounds_per_pass, lazy_from)
             assert np.array_equal(t.get_evaluation_points(), src)      # the factor tables are left unmodified
     with pytest.raises(zk_amd.ZkError):
         c.set_deg2_rounds_per_pass(3)
+
+
+# ---- the LDS-DMA forms of the big passes (the kernels the benchmark numbers come from), forced onto oracle-sized
+# tables through zk_ctx_set_dma_gates and compared with the oracle directly -------------------------------------
+@pytest.mark.parametrize("log_n", [7, 8, 14, 16, 18, 20])
+def test_block_sums_dma_vs_oracle(log_n):
+    c = zk_amd.Context(0)
+    c.set_dma_gates(0, 22, 22)  # k_block_sums_dma on every table whose blocks are whole 64-entry rows
+    n = 1 << log_n
+    t = O.gen_table(SEED + 140 + log_n, 0, n) if log_n > 8 else O.ints_to_mont(rand_table(n, 140 + log_n))
+    m = MLE(t, ctx=c)
+    c.forms_used()
+    e = m.round_sums()
+    assert c.forms_used() == {"sums_dma"}
+    assert list(e[0]) == list(O.mle_sum(t[: n // 2])) and list(e[1]) == list(O.mle_sum(t[n // 2:]))
+    # worst case for the carry chains: every entry p - 1
+    tm = O.ints_to_mont([P - 1] * 4096)
+    e = MLE(tm, ctx=c).round_sums()
+    assert O.mont_to_ints(e[0]) == [(P - 1) * 2048 % P] and O.mont_to_ints(e[1]) == [(P - 1) * 2048 % P]
+
+
+@pytest.mark.parametrize("log_n,wide,min_log_out,fold_batch", [(14, 6, 8, 2), (16, 8, 8, 2), (17, 8, 9, 3), (18, 8, 10, 4), (20, 8, 12, 4),
+                                                               (20, 7, 13, 4), (19, 5, 14, 2)])
+@pytest.mark.parametrize("stream_stores", [False, True])
+def test_sumcheck_dma_sums_and_dma_wide_fold_vs_oracle(log_n, wide, min_log_out, fold_batch, stream_stores):
+    """k_block_sums_dma and k_multifold_wide_dma<BIG> (the two sweeps of the 2^28 benchmark) on 2^14 .. 2^20 tables:
+    claim, coefficients and challenges against the oracle, and the form that ran is the one forced."""
+    c = zk_amd.Context(0)
+    c.set_dma_gates(0, 0 if stream_stores else 64, 22)
+    c.set_fold_batch(fold_batch, 0)
+    c.set_wide_fold(wide, min_log_out, 0)  # weights by scalar loads: the large-pass form
+    c.set_tail_fold(0)
+    table = O.gen_table(SEED + 160 + log_n, 3, 1 << log_n)
+    poly = MLE(table, ctx=c)
+    c.forms_used()
+    proof, ch = zk_amd.SumcheckProver.generate_sumcheck_proof(poly, return_challenges=True)
+    forms = c.forms_used()
+    assert "sums_dma" in forms and ("wide_dma_stream" if stream_stores else "wide_dma") in forms, forms
+    assert not forms & {"wide_reg", "wide_lds", "coop", "wide_dma" if stream_stores else "wide_dma_stream"}, forms
+    oclaim, ocoeffs, och = O.sumcheck_prove(table) if log_n <= 16 else O.sumcheck_prove_fast(table)
+    assert list(proof.initial_claim_sum) == list(oclaim)
+    assert np.array_equal(proof.round_polys, ocoeffs)
+    assert np.array_equal(ch, och)
+    assert np.array_equal(poly.get_evaluation_points(), table)  # the input table is left unmodified
+    if log_n <= 16:
+        pts = [r for r in ch]
+        assert np.array_equal(poly.evaluate(pts).get_evaluation_points(), O.mle_evaluate(table, pts))
+
+
+def test_dma_forms_on_worst_case_limbs():
+    """every entry p - 1 (all radix-2^28 columns at their bound) through the DMA sums and the DMA wide fold"""
+    c = zk_amd.Context(0)
+    c.set_dma_gates(0, 0, 22)
+    c.set_fold_batch(2, 0)
+    c.set_wide_fold(8, 8, 0)
+    c.set_tail_fold(0)
+    table = O.ints_to_mont([P - 1] * (1 << 16))
+    poly = MLE(table, ctx=c)
+    c.forms_used()
+    proof, ch = zk_amd.SumcheckProver.generate_sumcheck_proof(poly, return_challenges=True)
+    assert {"sums_dma", "wide_dma_stream"} <= c.forms_used()
+    oclaim, ocoeffs, och = O.sumcheck_prove(table)
+    assert list(proof.initial_claim_sum) == list(oclaim) and np.array_equal(proof.round_polys, ocoeffs) and np.array_equal(ch, och)
+
+
+@pytest.mark.parametrize("log_n", [8, 10, 13, 14, 16])
+@pytest.mark.parametrize("stream_stores", [False, True])
+@pytest.mark.parametrize("lazy_from", [0, 20])
+def test_sum2x2_dma_two_variable_fold_vs_oracle(log_n, stream_stores, lazy_from):
+    """the m = 2 LDS-DMA fold of the degree-2 branch (4 x 2^26 benchmark shape) on small tables against the oracle"""
+    c = zk_amd.Context(0)
+    c.set_dma_gates(27, 0 if stream_stores else 64, 0)
+    c.set_deg2_lazy_sums(lazy_from)
+    n = 1 << log_n
+    tabs = [O.gen_table(SEED + 180 + k, 0, n) for k in range(4)]
+    m = [MLE(t, ctx=c) for t in tabs]
+    f = zk_amd.SumPolynomial([zk_amd.ProductPolynomial(m[:2]), zk_amd.ProductPolynomial(m[2:])])
+    tr, otr = zk_amd.Transcript(), O.OTranscript()
+    c.forms_used()
+    proof, pts = zk_amd.SumcheckProver.generate_proof_for_partial_verify(O.fq1(5), f, tr)
+    forms = c.forms_used()
+    assert "fold2_dma" in forms, forms
+    ocoeffs, och = O.sumcheck_prove_sum([[tabs[0], tabs[1]], [tabs[2], tabs[3]]], O.fq1(5), otr)
+    assert np.array_equal(proof.round_polys, ocoeffs), log_n
+    assert np.array_equal(pts, och) and tr.peek_digest() == otr.peek_digest()
+    for t, src in zip(m, tabs):
+        assert np.array_equal(t.get_evaluation_points(), src)
+
+
+def test_dma_gate_arguments():
+    c = zk_amd.Context(0)
+    for bad in ((-1, 22, 22), (27, 65, 22), (27, 22, -3)):
+        with pytest.raises(zk_amd.ZkError):
+            c.set_dma_gates(*bad)
+    c.set_dma_gates(64, 64, 64)  # never
+    m = MLE(O.gen_table(SEED, 0, 1 << 14), ctx=c)
+    c.forms_used()
+    m.round_sums()
+    assert c.forms_used() == {"sums_reg"}

@@ -101,6 +101,8 @@ SYMBOLS = [
     ("zk_ctx_set_tail_fold", C.c_int, [_VP, C.c_int, C.c_int]),
     ("zk_ctx_set_deg2_rounds_per_pass", C.c_int, [_VP, C.c_int]),
     ("zk_ctx_set_deg2_lazy_sums", C.c_int, [_VP, C.c_int]),
+    ("zk_ctx_set_dma_gates", C.c_int, [_VP, C.c_int, C.c_int, C.c_int]),
+    ("zk_ctx_forms_used", C.c_uint, [_VP, C.c_int]),
     ("zk_prof_enable", C.c_int, [_VP, C.c_int]),
     ("zk_prof_reset", C.c_int, [_VP]),
     ("zk_prof_collect", C.c_int, [_VP]),

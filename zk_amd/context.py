@@ -8,6 +8,10 @@ from ._lib import check, lib
 KERNELS = {"block_sums": 0, "multifold": 1, "fold": 2, "eval3": 3, "fold4_eval3": 4, "sum9": 5, "fold2x4_sum9": 6, "multifold_wide": 7, "multifold_tail": 8}
 
 
+FORMS = ["sums_dma", "sums_reg", "wide_dma", "wide_dma_stream", "wide_reg", "wide_lds", "coop", "fold2_dma", "fold2_reg", "sum9_lazy", "sum9",
+         "fold2_sum9"]
+
+
 class Context:
     def __init__(self, device_id: int = 0, _stream=None):
         h = C.c_void_p()
@@ -55,6 +59,15 @@ class Context:
     def set_deg2_lazy_sums(self, from_log: int = 18):
         """Degree-2 prover: nine-sum sweeps over >= 2^from_log quarter-entries use unreduced accumulation (negative: never)."""
         check(lib().zk_ctx_set_deg2_lazy_sums(self.h, from_log))
+
+    def set_dma_gates(self, sums_from_log: int = 27, wide_stream_from_log: int = 22, fold2_from_log: int = 22):
+        """Size thresholds (log2 entries, 64 = never) of the LDS-DMA forms of the big passes.  Proof bytes do not depend on it."""
+        check(lib().zk_ctx_set_dma_gates(self.h, sums_from_log, wide_stream_from_log, fold2_from_log))
+
+    def forms_used(self, reset: bool = True) -> set:
+        """Names of the kernel forms launched from this thread since the last reset."""
+        bits = lib().zk_ctx_forms_used(self.h, int(reset))
+        return {name for k, name in enumerate(FORMS) if bits >> k & 1}
 
     # ---- measurement hooks
     def prof_enable(self, on: bool = True):

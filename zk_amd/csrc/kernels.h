@@ -16,8 +16,32 @@ static constexpr int kMaxBlocks = 2048;
 
 static constexpr int kMaxFoldBatch = 8;  // rounds bound per pass (k_multifold_wide)
 static constexpr int kMaxLazyBatch = 4;  // ... by the kernel-argument-weight forms (k_multifold<M>, k_multifold_lazy<M,G>)
+// Which form of a pass a launcher picked, OR-ed into g_forms (per host thread) since the caller last cleared it: the
+// parity tests force every form onto oracle-sized tables through the zk_ctx_set_* thresholds and assert that the form
+// under test is the one that ran (zk_ctx_forms_used).
+enum Form : unsigned {
+    kFormSumsDma = 1u << 0,       // k_block_sums_dma
+    kFormSumsReg = 1u << 1,       // k_block_sums
+    kFormWideDma = 1u << 2,       // k_multifold_wide_dma<false>
+    kFormWideDmaStream = 1u << 3, // k_multifold_wide_dma<true> (streaming stores)
+    kFormWideReg = 1u << 4,       // k_multifold_wide
+    kFormWideLds = 1u << 5,       // k_multifold_wide_lds
+    kFormCoop = 1u << 6,          // k_multifold_coop
+    kFormFold2Dma = 1u << 7,      // m = 2 LDS-DMA fold of the degree-2 branch
+    kFormFold2Reg = 1u << 8,      // k_fold2_tables
+    kFormSum9Lazy = 1u << 9,      // k_sum9_lazy
+    kFormSum9 = 1u << 10,         // k_sum9<YSPLIT>
+    kFormFold2Sum9 = 1u << 11,    // k_fold2_sum9 (fold fused with the next nine sums)
+};
+extern thread_local unsigned g_forms;
+// Size thresholds of the LDS-DMA forms (log2 of entries; defaults = the measured break-even points)
+struct DmaGates {
+    int sums_from_log = 27;        // block sums by LDS-DMA from tables of 2^k entries
+    int wide_stream_from_log = 22; // wide fold: streaming (nontemporal) stores from 2^k outputs
+    int fold2_from_log = 22;       // degree-2 two-variable fold by LDS-DMA from 2^k outputs per table
+};
 // out[b] (b < 2^log_ob) = sum of the b-th contiguous block of T (L entries); partials is scratch
-int launch_block_sums(const void* T, size_t L, int log_ob, void* partials, void* out, hipStream_t st);
+int launch_block_sums(const void* T, size_t L, int log_ob, void* partials, void* out, hipStream_t st, const DmaGates& gates = DmaGates());
 // dst (Lout entries) = src (Lout << m entries) with its top m variables bound to r[0..m) (4 limbs each);
 // out[c] (c < 2^log_ob) = sum of the c-th contiguous block of dst.  db: register double-buffering.
 int launch_multifold(int m, const void* src, void* dst, size_t Lout, const uint64_t* r, int log_ob, bool db, void* partials, void* out,
@@ -33,7 +57,8 @@ int launch_multifold_lazy(int m, int group, const void* src, void* dst, size_t L
 static constexpr int kWideWeightWords = (1 << kMaxFoldBatch) * 10;
 // Outputs below 2^coop_below_log entries (m >= 6): one wave per output (k_multifold_coop); 0 = never.
 int launch_multifold_wide(int m, const void* src, void* dst, size_t Lout, const uint64_t* r, const uint64_t two24[4], void* wbuf,
-                          int lds_below_log, int coop_below_log, int log_ob, void* partials, void* out, hipStream_t st);
+                          int lds_below_log, int coop_below_log, int log_ob, void* partials, void* out, hipStream_t st,
+                          const DmaGates& gates = DmaGates());
 void launch_fold_var(const void* src, void* dst, size_t n_out, int log_s, const uint64_t r[4], hipStream_t st);
 void launch_reduce_partials(const void* partials, int nblocks, int ns, void* out, hipStream_t st);
 int launch_sum_all(const void* T, size_t n, void* partials, hipStream_t st);
@@ -49,7 +74,8 @@ void launch_sum9(const void* const t[4], size_t q, const uint64_t fix24[4], int 
 // bind the two top variables of four tables of 4*outlen entries (w28: the 4 eq weights as for launch_multifold_lazy)
 // into d[] (outlen entries each)
 // wbuf (device, >= 40 u32) and partials (>= 1024 elements) are scratch for the large-table form; either may be null (then never used)
-void launch_fold2_tables(const void* const s[4], void* const d[4], size_t outlen, const uint32_t* w28, void* wbuf, void* partials, hipStream_t st);
+void launch_fold2_tables(const void* const s[4], void* const d[4], size_t outlen, const uint32_t* w28, void* wbuf, void* partials, hipStream_t st,
+                         const DmaGates& gates = DmaGates());
 // out[k*n + i] = t[k][i], k < 4, i < n
 void launch_gather4(const void* const t[4], size_t n, void* out, hipStream_t st);
 void launch_from_le32(const void* in, void* out, size_t n, hipStream_t st);

@@ -16,6 +16,8 @@
 
 namespace zkk {
 
+thread_local unsigned g_forms = 0;
+
 static constexpr int kThreads = 256;
 
 // block-wide sums of NS accumulators; thread 0 of the block writes partials[blockIdx.x*NS + s]
@@ -1034,17 +1036,19 @@ static inline int grid_blocks(size_t Lb, int log_ob) {
     if (per < 1) per = 1;
     return (int)(per << log_ob);
 }
-int launch_block_sums(const void* T, size_t L, int log_ob, void* partials, void* out, hipStream_t st) {
+int launch_block_sums(const void* T, size_t L, int log_ob, void* partials, void* out, hipStream_t st, const DmaGates& gates) {
     const size_t Lb0 = L >> log_ob;
     // large tables: LDS-DMA stream with the nt policy, 6.7 vs 6.1 TB/s at 2^28 entries; it wins from 2^27 entries
     // (0.667 vs 0.722 ms), ties at 2^25 and loses at 2^26 and below (its 64 KiB of LDS per workgroup cap the waves per CU)
-    if (Lb0 % 64 == 0 && L >= ((size_t)1 << 27)) {
+    if (Lb0 % 64 == 0 && gates.sums_from_log < 63 && L >= ((size_t)1 << std::max(gates.sums_from_log, 0))) {
         int g = grid_blocks(Lb0 / 64, log_ob);
+        g_forms |= kFormSumsDma;
         hipLaunchKernelGGL((k_block_sums_dma<8, 2>), dim3(g), dim3(kThreads), 0, st, (const fq*)T, L, log_ob, (fq*)partials);
         hipLaunchKernelGGL(k_reduce_groups, dim3(1 << log_ob), dim3(kThreads), 0, st, (const fq*)partials, g >> log_ob, (fq*)out);
         return g;
     }
     int g = grid_blocks(L >> log_ob, log_ob);
+    g_forms |= kFormSumsReg;
     hipLaunchKernelGGL(k_block_sums, dim3(g), dim3(kThreads), 0, st, (const fq*)T, L, log_ob, (fq*)partials);
     hipLaunchKernelGGL(k_reduce_groups, dim3(1 << log_ob), dim3(kThreads), 0, st, (const fq*)partials, g >> log_ob, (fq*)out);
     return g;
@@ -1114,7 +1118,8 @@ static inline int grid_blocks_wide(size_t Lb, int log_ob) {
     return (int)(per << log_ob);
 }
 int launch_multifold_wide(int m, const void* src, void* dst, size_t Lout, const uint64_t* r, const uint64_t two24[4], void* wbuf,
-                          int lds_below_log, int coop_below_log, int log_ob, void* partials, void* out, hipStream_t st) {
+                          int lds_below_log, int coop_below_log, int log_ob, void* partials, void* out, hipStream_t st, const DmaGates& gates) {
+    const bool stream_stores = gates.wide_stream_from_log < 63 && Lout >= ((size_t)1 << std::max(gates.wide_stream_from_log, 0));
     if (m < 3 || m > kMaxFoldBatch || (Lout >> log_ob) >= ((size_t)1 << 31)) return -1;
     ChalWide ch;
     for (int l = 0; l < kMaxFoldBatch; ++l) ch.r[l] = l < m ? to_fq(r + 4 * l) : fq{};
@@ -1124,12 +1129,14 @@ int launch_multifold_wide(int m, const void* src, void* dst, size_t Lout, const 
         if (per > cap) per = cap;
         if (per < 1) per = 1;
         const int g = (int)(per << log_ob);
+        g_forms |= kFormCoop;
         hipLaunchKernelGGL(k_multifold_coop, dim3(g), dim3(kThreads), 0, st, (const fq*)src, (fq*)dst, Lout, ch, m, log_ob, (fq*)partials);
         hipLaunchKernelGGL(k_reduce_groups, dim3(1 << log_ob), dim3(kThreads), 0, st, (const fq*)partials, g >> log_ob, (fq*)out);
         return g;
     }
     if (lds_below_log > 0 && (lds_below_log >= 63 || Lout < ((size_t)1 << lds_below_log))) { // small output: weights per workgroup in LDS
         int g = grid_blocks(Lout >> log_ob, log_ob);
+        g_forms |= kFormWideLds;
         hipLaunchKernelGGL(k_multifold_wide_lds, dim3(g), dim3(kThreads), 0, st, (const fq*)src, (fq*)dst, Lout, ch, m, log_ob, (fq*)partials);
         hipLaunchKernelGGL(k_reduce_groups, dim3(1 << log_ob), dim3(kThreads), 0, st, (const fq*)partials, g >> log_ob, (fq*)out);
         return g;
@@ -1141,7 +1148,8 @@ int launch_multifold_wide(int m, const void* src, void* dst, size_t Lout, const 
         if (per > cap) per = cap;
         if (per < 1) per = 1;
         const int g = (int)(per << log_ob);
-        if (Lout >= ((size_t)1 << 22))
+        g_forms |= stream_stores ? kFormWideDmaStream : kFormWideDma;
+        if (stream_stores)
             hipLaunchKernelGGL((k_multifold_wide_dma<true, 4>), dim3(g), dim3(kThreads), 0, st, (const fq*)src, (fq*)dst, Lout, (const u32*)wbuf,
                                m, log_ob, (fq*)partials);
         else
@@ -1151,7 +1159,8 @@ int launch_multifold_wide(int m, const void* src, void* dst, size_t Lout, const 
         return g;
     }
     int g = grid_blocks_wide(Lout >> log_ob, log_ob);
-    if (Lout >= ((size_t)1 << 22))
+    g_forms |= kFormWideReg;
+    if (stream_stores)
         hipLaunchKernelGGL(k_multifold_wide<true>, dim3(g), dim3(kThreads), 0, st, (const fq*)src, (fq*)dst, Lout, (const u32*)wbuf, m, log_ob,
                            (fq*)partials);
     else
@@ -1212,6 +1221,7 @@ void launch_sum9(const void* const t[4], size_t q, const uint64_t fix24[4], int 
         size_t gx = (q + 63) / 64;
         if (gx > (size_t)kMaxBlocks9) gx = kMaxBlocks9;
         fq* u = (fq*)partials + (size_t)18 * kMaxBlocks9; // nine U sums, behind the partials
+        g_forms |= kFormSum9Lazy;
         hipLaunchKernelGGL(k_sum9_lazy, dim3((unsigned)gx, 2), dim3(64, 9), 0, st, T, q, to_fq(fix24), (fq*)partials);
         hipLaunchKernelGGL(k_reduce9, dim3(9), dim3(kThreads), 0, st, (const fq*)partials, (int)gx, 1, u);
         hipLaunchKernelGGL(k_sum9_from_u, dim3(1), dim3(64), 0, st, (const fq*)u, (fq*)out);
@@ -1220,6 +1230,7 @@ void launch_sum9(const void* const t[4], size_t q, const uint64_t fix24[4], int 
     size_t gx = (q + kThreads - 1) / kThreads;
     if (gx < 1) gx = 1;
     if (gx > (size_t)kMaxBlocks9) gx = kMaxBlocks9;
+    g_forms |= kFormSum9;
     const bool ysplit = q < ((size_t)1 << 21); // small tables: three times the lanes, tables read twice (mostly cache-resident)
     if (ysplit) hipLaunchKernelGGL((k_sum9<true>), dim3((unsigned)gx, 6), dim3(kThreads), 0, st, T, q, (fq*)partials);
     else hipLaunchKernelGGL((k_sum9<false>), dim3((unsigned)gx, 2), dim3(kThreads), 0, st, T, q, (fq*)partials);
@@ -1234,14 +1245,17 @@ void launch_gather4(const void* const t[4], size_t n, void* out, hipStream_t st)
 __global__ void __launch_bounds__(64) k_store_w28x4(W28<2> W, u32* __restrict__ out) {
     if (threadIdx.x < 40) out[threadIdx.x] = W.w[threadIdx.x / 10][threadIdx.x % 10];
 }
-void launch_fold2_tables(const void* const s[4], void* const d[4], size_t outlen, const uint32_t* w28, void* wbuf, void* partials, hipStream_t st) {
+void launch_fold2_tables(const void* const s[4], void* const d[4], size_t outlen, const uint32_t* w28, void* wbuf, void* partials, hipStream_t st,
+                         const DmaGates& gates) {
     Tab4 S;
     Tab4w D;
     for (int k = 0; k < 4; ++k) { S.t[k] = (const fq*)s[k]; D.t[k] = (fq*)d[k]; }
     W28<2> W;
     for (int b = 0; b < 4; ++b)
         for (int j = 0; j < 10; ++j) W.w[b][j] = w28[b * 10 + j];
-    if (wbuf && partials && outlen % 64 == 0 && outlen >= ((size_t)1 << 22)) {
+    if (wbuf && partials && outlen % 64 == 0 && gates.fold2_from_log < 63 && outlen >= ((size_t)1 << std::max(gates.fold2_from_log, 0))) {
+        g_forms |= kFormFold2Dma;
+        const bool stream_stores = gates.wide_stream_from_log < 63 && outlen >= ((size_t)1 << std::max(gates.wide_stream_from_log, 0));
         // the largest tables: each table is one m = 2 pass of the LDS-DMA fold (its block sum is not used).  The pass stays
         // bound by its store stream (1 store per 4 reads): 4.67 -> 4.85 TB/s only, and slower than the lane-per-output
         // kernel below 2^22 outputs per table
@@ -1249,7 +1263,7 @@ void launch_fold2_tables(const void* const s[4], void* const d[4], size_t outlen
         size_t per = (outlen / 64 + 3) / 4;
         if (per > 1024) per = 1024;
         for (int k = 0; k < 4; ++k) {
-            if (outlen >= ((size_t)1 << 22))
+            if (stream_stores)
                 hipLaunchKernelGGL((k_multifold_wide_dma<true, 4>), dim3((unsigned)per), dim3(kThreads), 0, st, S.t[k], D.t[k], outlen, (const u32*)wbuf, 2,
                                    0, (fq*)partials);
             else
@@ -1261,6 +1275,7 @@ void launch_fold2_tables(const void* const s[4], void* const d[4], size_t outlen
     size_t gx = (outlen + kThreads - 1) / kThreads;
     if (gx < 1) gx = 1;
     if (gx > (size_t)kMaxBlocks) gx = kMaxBlocks;
+    g_forms |= kFormFold2Reg;
     hipLaunchKernelGGL(k_fold2_tables, dim3((unsigned)gx, 4), dim3(kThreads), 0, st, S, D, outlen, W);
 }
 void launch_from_le32(const void* in, void* out, size_t n, hipStream_t st) {

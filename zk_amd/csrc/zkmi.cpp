@@ -354,7 +354,7 @@ int zk_mle_round_sums(const zk_mle* m, uint64_t out[8]) {
     if (rc) return rc;
     {
         ProfScope ps(c, ZK_K_BLOCK_SUMS, (uint64_t)m->len * 32);
-        zkk::launch_block_sums(m->d, m->len, 1, c->partials, c->sums_host_dev, c->stream);
+        zkk::launch_block_sums(m->d, m->len, 1, c->partials, c->sums_host_dev, c->stream, c->gates);
     }
     Fq e[2];
     HIPCHK(c, hipGetLastError());
@@ -462,7 +462,7 @@ int zk_shard_block_sums(zk_shard* s, int m, void* sums_dev_out) {
     const size_t len = (size_t)1 << s->ell;
     {
         ProfScope ps(c, ZK_K_BLOCK_SUMS, (uint64_t)len * 32);
-        zkk::launch_block_sums(s->cur, len, m, c->partials, sums_dev_out, c->stream);
+        zkk::launch_block_sums(s->cur, len, m, c->partials, sums_dev_out, c->stream, c->gates);
     }
     HIPCHK(c, hipGetLastError());
     return ZK_OK;
@@ -488,7 +488,7 @@ int zk_shard_fold(zk_shard* s, int m, const uint64_t* r_mont, int m_next, void* 
         ProfScope ps(c, m <= zkk::kMaxLazyBatch ? ZK_K_MULTIFOLD : tail ? ZK_K_MULTIFOLD_TAIL : ZK_K_MULTIFOLD_WIDE,
                      (uint64_t)(lout << m) * 32 + (uint64_t)lout * 32);
         if (m > zkk::kMaxLazyBatch) {
-            launched = zkk::launch_multifold_wide(m, s->cur, dst, lout, r_mont, c->two24, c->wide_w, c->wide_lds_below_log, c->tail_max_log > 0 ? c->tail_out_below_log : 0, m_next, c->partials, sums, c->stream);
+            launched = zkk::launch_multifold_wide(m, s->cur, dst, lout, r_mont, c->two24, c->wide_w, c->wide_lds_below_log, c->tail_max_log > 0 ? c->tail_out_below_log : 0, m_next, c->partials, sums, c->stream, c->gates);
         } else if (c->lazy && m >= 2) {
             uint32_t w28[(1 << zkk::kMaxLazyBatch) * 10];
             eq_weights28(r_mont, (unsigned)m, w28);
@@ -743,7 +743,7 @@ static int prove_sum2x2_pairs(zk_ctx* c, const void* const tables[4], size_t len
         eq_weights28(rs, 2, w28);
         {
             ProfScope ps(c, ZK_K_FOLD2X4_SUM9, (uint64_t)curlen * 32 * 4 + (uint64_t)outlen * 32 * 4);
-            zkk::launch_fold2_tables(cur, dst, outlen, w28, c->wide_w, c->partials, c->stream);
+            zkk::launch_fold2_tables(cur, dst, outlen, w28, c->wide_w, c->partials, c->stream, c->gates);
         }
         if (outlen > kHostTail) {
             ProfScope ps(c, ZK_K_SUM9, (uint64_t)outlen * 32 * 4);
@@ -917,7 +917,7 @@ int zk_shard4_fold2(zk_shard4* s, const uint64_t r2[8], void* sums_dev_out) {
     eq_weights28(r2, 2, w28);
     {
         ProfScope ps(c, ZK_K_FOLD2X4_SUM9, (uint64_t)s->len * 32 * 4 + (uint64_t)outlen * 32 * 4);
-        zkk::launch_fold2_tables(s->cur, dst, outlen, w28, c->wide_w, c->partials, c->stream);
+        zkk::launch_fold2_tables(s->cur, dst, outlen, w28, c->wide_w, c->partials, c->stream, c->gates);
     }
     if (sums_dev_out && outlen >= 4) {
         ProfScope ps(c, ZK_K_SUM9, (uint64_t)outlen * 32 * 4);
@@ -1027,6 +1027,21 @@ int zk_ctx_set_deg2_rounds_per_pass(zk_ctx* c, int rounds) {
     if (!c || (rounds != 1 && rounds != 2)) return ZK_E_ARG;
     c->deg2_pairs = rounds == 2;
     return ZK_OK;
+}
+int zk_ctx_set_dma_gates(zk_ctx* c, int sums_from_log, int wide_stream_from_log, int fold2_from_log) {
+    if (!c || sums_from_log < 0 || sums_from_log > 64 || wide_stream_from_log < 0 || wide_stream_from_log > 64 || fold2_from_log < 0 ||
+        fold2_from_log > 64)
+        return ZK_E_ARG;
+    c->gates.sums_from_log = sums_from_log;
+    c->gates.wide_stream_from_log = wide_stream_from_log;
+    c->gates.fold2_from_log = fold2_from_log;
+    return ZK_OK;
+}
+unsigned zk_ctx_forms_used(zk_ctx* c, int reset) {
+    (void)c; // the record is per host thread (a context is used from one thread at a time)
+    const unsigned f = zkk::g_forms;
+    if (reset) zkk::g_forms = 0;
+    return f;
 }
 int zk_prof_enable(zk_ctx* c, int on) {
     if (!c) return ZK_E_ARG;

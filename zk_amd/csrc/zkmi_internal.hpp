@@ -75,6 +75,7 @@ struct zk_ctx {
     uint64_t two24[4];           // 2^24 in Montgomery form (radix-2^28 reductions divide by 2^280, not 2^256)
     bool deg2_pairs = true;      // degree-2 prover: two rounds per device pass (k_sum9 / k_fold2x4_sum9)
     int lazy_group = 4;          // elements per register load buffer in k_multifold_lazy (2 or 4)
+    zkk::DmaGates gates;         // size thresholds of the LDS-DMA forms (zk_ctx_set_dma_gates)
     void* work[2] = {nullptr, nullptr};
     size_t work_cap[2] = {0, 0}; // bytes
     void* stage = nullptr;       // kChunkElems elements
