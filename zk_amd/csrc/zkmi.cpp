@@ -418,6 +418,21 @@ void host_rounds(zk_transcript* tr, const uint64_t* sums, int world, unsigned m,
     if (folded_out)
         for (int q = 0; q < world; ++q) zkh::store(folded_out + 4 * q, per[(size_t)q * nb]);
 }
+// one fold pass: dst (lout entries) = src (lout << m entries) with its top m variables bound at r, sums (2^m_next elements)
+// = the block sums of dst.  `k` supplies the schedule knobs only (kernel form thresholds); every buffer is an argument, so
+// the entry point that allocates nothing shares this dispatch.  Returns the workgroups launched, < 0 if no kernel takes the shape.
+int fold_pass(const zk_ctx& k, const uint64_t two24[4], const void* src, void* dst, size_t lout, int m, const uint64_t* r_mont, int m_next,
+              void* partials, void* wide_w, void* sums, hipStream_t stream) {
+    if (m > zkk::kMaxLazyBatch)
+        return zkk::launch_multifold_wide(m, src, dst, lout, r_mont, two24, wide_w, k.wide_lds_below_log, k.tail_max_log > 0 ? k.tail_out_below_log : 0,
+                                          m_next, partials, sums, stream, k.gates);
+    if (k.lazy && m >= 2) {
+        uint32_t w28[(1 << zkk::kMaxLazyBatch) * 10];
+        eq_weights28(r_mont, (unsigned)m, w28);
+        return zkk::launch_multifold_lazy(m, k.lazy_group, src, dst, lout, w28, m_next, partials, sums, stream);
+    }
+    return zkk::launch_multifold(m, src, dst, lout, r_mont, m_next, k.double_buffer, partials, sums, stream);
+}
 } // namespace
 
 
@@ -487,15 +502,7 @@ int zk_shard_fold(zk_shard* s, int m, const uint64_t* r_mont, int m_next, void* 
         const bool tail = m >= 6 && c->tail_max_log > 0 && lout < ((size_t)1 << c->tail_out_below_log); // as launch_multifold_wide decides
         ProfScope ps(c, m <= zkk::kMaxLazyBatch ? ZK_K_MULTIFOLD : tail ? ZK_K_MULTIFOLD_TAIL : ZK_K_MULTIFOLD_WIDE,
                      (uint64_t)(lout << m) * 32 + (uint64_t)lout * 32);
-        if (m > zkk::kMaxLazyBatch) {
-            launched = zkk::launch_multifold_wide(m, s->cur, dst, lout, r_mont, c->two24, c->wide_w, c->wide_lds_below_log, c->tail_max_log > 0 ? c->tail_out_below_log : 0, m_next, c->partials, sums, c->stream, c->gates);
-        } else if (c->lazy && m >= 2) {
-            uint32_t w28[(1 << zkk::kMaxLazyBatch) * 10];
-            eq_weights28(r_mont, (unsigned)m, w28);
-            launched = zkk::launch_multifold_lazy(m, c->lazy_group, s->cur, dst, lout, w28, m_next, c->partials, sums, c->stream);
-        } else {
-            launched = zkk::launch_multifold(m, s->cur, dst, lout, r_mont, m_next, c->double_buffer, c->partials, sums, c->stream);
-        }
+        launched = fold_pass(*c, c->two24, s->cur, dst, lout, m, r_mont, m_next, c->partials, c->wide_w, sums, c->stream);
     }
     HIPCHK(c, hipGetLastError());
     if (launched < 0) {
