@@ -45,7 +45,8 @@ typedef enum zk_status {
     ZK_E_HIP = 7,          /* a HIP runtime call failed; zk_last_error() has the text */
     ZK_E_ARG = 8,          /* NULL pointer / bad argument */
     ZK_E_NO_DEVICE = 9,    /* no gfx950 device: the library refuses to run (no CPU path) */
-    ZK_E_COMM = 10         /* collective (RCCL) failure */
+    ZK_E_COMM = 10,        /* collective (RCCL) failure */
+    ZK_E_TOO_LARGE = 11    /* input beyond the maximum of the entry point that allocates nothing */
 } zk_status;
 
 typedef struct zk_ctx zk_ctx;               /* one GPU: device, stream, scratch */
@@ -167,6 +168,20 @@ int zk_shard_block_sums(zk_shard *s, int m, void *sums_dev_out);
 /* bind the top m variables at r[0..m) (m x partially_evaluate((0, r)), evaluation_form.rs:163-192) and
  * leave the 2^m_next block sums of the result in sums_dev_out (m_next = 0: none) */
 int zk_shard_fold(zk_shard *s, int m, const uint64_t *r_mont, int m_next, void *sums_dev_out);
+
+/* zk_shard_fold for callers that cannot allocate.  NO COUNTERPART IN THE REFERENCE: it exists for callers that
+ * cannot call hipMalloc -- code under HIP graph capture, tight serving loops, harnesses that forbid allocation.  Same
+ * pass, same kernels, same results as zk_shard_fold with the default schedule knobs: dst_dev (len >> m elements) =
+ * src_dev (len elements, a power of two) with its top m variables bound at r_mont[0..m) (1 <= m <= 8), and
+ * sums_dev_out (2^m_next elements, device; may be NULL when m_next = 0) = the block sums of dst_dev.  No context: the
+ * pass runs on the calling thread's current device, asynchronously on hip_stream.  It calls no hipMalloc / hipFree /
+ * allocating routine: its scratch (per-workgroup partial sums, the eq weights of a wide pass; 138 KiB) is a file-scope
+ * __device__ array that every GPU the library runs on holds until the process ends.  len is limited to
+ * 2^ZK_NOALLOC_MAX_LOG_LEN entries (ZK_E_TOO_LARGE beyond).  All calls on one GPU share that GPU's array: calls that
+ * overlap on one GPU (two streams, two threads) race -- serialise them.  Pointers must be 16-byte aligned. */
+#define ZK_NOALLOC_MAX_LOG_LEN 30
+int zk_fold_block_sums_noalloc(void *hip_stream, const void *src_dev, size_t len, int m, const uint64_t *r_mont,
+                               void *dst_dev, int m_next, void *sums_dev_out);
 
 /* The SumPolynomial branch (prover.rs:89-107, :131-139) in steps, for four factor tables sharded the same
  * way.  Per round every rank contributes its share of the three evaluations (3 x 32 B, all-gathered by

@@ -17,7 +17,7 @@ u8p = C.POINTER(C.c_uint8)
 
 STATUS_NAMES = {
     0: "ZK_OK", 1: "ZK_E_NOT_POW2", 2: "ZK_E_POINTS_LEN", 3: "ZK_E_LEN_MISMATCH", 4: "ZK_E_LAYER_OOB",
-    5: "ZK_E_DEGREE", 6: "ZK_E_ALLOC", 7: "ZK_E_HIP", 8: "ZK_E_ARG", 9: "ZK_E_NO_DEVICE", 10: "ZK_E_COMM",
+    5: "ZK_E_DEGREE", 6: "ZK_E_ALLOC", 7: "ZK_E_HIP", 8: "ZK_E_ARG", 9: "ZK_E_NO_DEVICE", 10: "ZK_E_COMM", 11: "ZK_E_TOO_LARGE",
 }
 
 # every symbol include/zkmi.h declares: (name, restype, argtypes)
@@ -71,6 +71,7 @@ SYMBOLS = [
     ("zk_shard_copy_table", C.c_int, [_VP, _VP]),
     ("zk_shard_block_sums", C.c_int, [_VP, C.c_int, _VP]),
     ("zk_shard_fold", C.c_int, [_VP, C.c_int, u64p, C.c_int, _VP]),
+    ("zk_fold_block_sums_noalloc", C.c_int, [_VP, _VP, C.c_size_t, C.c_int, u64p, _VP, C.c_int, _VP]),
     ("zk_shard4_begin", C.c_int, [_VP, C.POINTER(_VP), C.POINTER(_VP)]),
     ("zk_shard4_end", None, [_VP]),
     ("zk_shard4_len", C.c_size_t, [_VP]),

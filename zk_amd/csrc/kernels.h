@@ -83,4 +83,13 @@ void launch_to_le32(const void* in, void* out, size_t n, hipStream_t st);
 void launch_generate(void* out, uint64_t seed, uint64_t first, uint64_t step, size_t n, hipStream_t st);
 void launch_modmul_probe(void* io, int blocks, int iters, hipStream_t st);
 
+// ---- static scratch of the entry point that allocates nothing (zk_fold_block_sums_noalloc) ----
+// One file-scope __device__ array per GPU (kernels.hip): [0, kStaticPartialsBytes) per-workgroup partial sums of a fold
+// pass, then the eq weights of a wide pass, then one element for the block sum of a pass that asks for none.
+static constexpr size_t kStaticPartialsBytes = (size_t)2 * kMaxBlocks * 32;
+static constexpr size_t kStaticWeightsBytes = (size_t)kWideWeightWords * sizeof(uint32_t);
+static constexpr size_t kStaticScratchBytes = kStaticPartialsBytes + kStaticWeightsBytes + 256;
+// Device address of the CURRENT device's copy of the array (hipGetSymbolAddress, once per device, cached).
+hipError_t static_scratch_ptr(void** out);
+
 } // namespace zkk

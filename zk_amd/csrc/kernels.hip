@@ -11,6 +11,7 @@
 // small second-stage kernel folds the partials (fixed order: results are bit-reproducible).
 #include <algorithm>
 #include <cstdlib>
+#include <mutex>
 #include "fq_dev.hpp"
 #include "kernels.h"
 
@@ -1289,6 +1290,32 @@ void launch_generate(void* out, uint64_t seed, uint64_t first, uint64_t step, si
 }
 void launch_modmul_probe(void* io, int blocks, int iters, hipStream_t st) {
     hipLaunchKernelGGL(k_modmul_probe, dim3(blocks), dim3(kThreads), 0, st, (fq*)io, iters);
+}
+
+// ---- static scratch (zk_fold_block_sums_noalloc: the entry point that allocates nothing) ----------------------
+// Every GPU the library runs on holds its own copy of this array, at its own address, until the process ends.  In host
+// code the name `scratch` is only a stand-in for the symbol: the device address comes from hipGetSymbolAddress, taken
+// once per device with that device current, and host code uses that pointer (kernel arguments) -- never the name.
+static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
+
+hipError_t static_scratch_ptr(void** out) {
+    constexpr int kMaxDevices = 64;
+    static std::mutex mu;
+    static void* ptrs[kMaxDevices] = {};
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= kMaxDevices) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!ptrs[dev]) {
+        void* p = nullptr;
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return e;
+        if (!p) return hipErrorInvalidSymbol;
+        ptrs[dev] = p;
+    }
+    *out = ptrs[dev];
+    return hipSuccess;
 }
 
 } // namespace zkk

@@ -21,6 +21,7 @@ const char* zk_strerror(int s) {
         case ZK_E_ARG: return "bad argument";
         case ZK_E_NO_DEVICE: return "no gfx950 device available (this library has no CPU path)";
         case ZK_E_COMM: return "collective communication error";
+        case ZK_E_TOO_LARGE: return "input larger than the maximum the static scratch buffer is sized for";
         default: return "unknown status";
     }
 }
@@ -48,7 +49,8 @@ static int ctx_create(int device_id, bool own_stream, hipStream_t stream, zk_ctx
         rc = ZK_E_HIP;
         return true;
     };
-    if (fail(hipSetDevice(device_id), "hipSetDevice") ||
+    void* static_scratch = nullptr; // set-up of the no-allocation entry point's scratch for this device, with it current
+    if (fail(hipSetDevice(device_id), "hipSetDevice") || fail(zkk::static_scratch_ptr(&static_scratch), "hipGetSymbolAddress(scratch)") ||
         (own_stream && fail(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking), "hipStreamCreate")) ||
         fail(hipMalloc(&c->partials, (size_t)(std::max(zkk::kMaxBlocks * 3, zkk::kMaxBlocks9 * 18) + 16) * kElem), "hipMalloc partials") ||
         fail(hipMalloc(&c->sums_dev, kSums * kElem), "hipMalloc sums") ||
@@ -513,6 +515,34 @@ int zk_shard_fold(zk_shard* s, int m, const uint64_t* r_mont, int m_next, void* 
     s->ell = ell_out;
     ++s->pass;
     return ZK_OK;
+}
+
+// The fold pass of zk_shard_fold for callers that cannot allocate: every buffer it touches is an argument or the
+// library's static __device__ scratch array (kernels.hip).  No hipMalloc / hipFree / allocating call on this path;
+// asynchronous on `hip_stream`, device = the calling thread's current device.
+int zk_fold_block_sums_noalloc(void* hip_stream, const void* src_dev, size_t len, int m, const uint64_t* r_mont, void* dst_dev, int m_next,
+                               void* sums_dev_out) {
+    if (!src_dev || !dst_dev || !r_mont || ((uintptr_t)src_dev | (uintptr_t)dst_dev | (uintptr_t)sums_dev_out) % 16) return ZK_E_ARG;
+    if (!is_pow2(len)) return ZK_E_NOT_POW2;
+    if (len > ((size_t)1 << ZK_NOALLOC_MAX_LOG_LEN)) return ZK_E_TOO_LARGE;
+    const unsigned ell = ilog2(len);
+    if (m < 1 || m > zkk::kMaxFoldBatch || (unsigned)m > ell) return ZK_E_ARG;
+    if (m_next < 0 || m_next > zkk::kMaxFoldBatch || (unsigned)(m + m_next) > ell || (m_next && !sums_dev_out)) return ZK_E_ARG;
+    void* base = nullptr; // this device's copy of the array (first call on a device: hipGetSymbolAddress; cached after that)
+    if (zkk::static_scratch_ptr(&base) != hipSuccess) return ZK_E_HIP;
+    void* partials = base;
+    void* wide_w = (uint8_t*)base + zkk::kStaticPartialsBytes;
+    void* own_sum = (uint8_t*)base + zkk::kStaticPartialsBytes + zkk::kStaticWeightsBytes; // m_next = 0: the pass still writes one total
+    // Every scratch word a kernel of the pass reads was written earlier in the same pass (each workgroup stores its partial
+    // unconditionally, k_eq_weights28 writes all 2^m weights), so nothing has to start at zero.
+    static const zk_ctx defaults{}; // the library's default schedule knobs (no device state)
+    uint64_t two24[4];
+    zkh::store(two24, zkh::from_u64((uint64_t)1 << 24));
+    const size_t lout = len >> m;
+    const int launched = fold_pass(defaults, two24, src_dev, dst_dev, lout, m, r_mont, m_next, partials, wide_w, m_next ? sums_dev_out : own_sum,
+                                   (hipStream_t)hip_stream);
+    if (launched < 0) return ZK_E_ARG;
+    return hipGetLastError() == hipSuccess ? ZK_OK : ZK_E_HIP;
 }
 
 int zk_sumcheck_prove_mle(zk_ctx* c, const zk_mle* poly, int absorb_table, zk_transcript* transcript,
