@@ -164,3 +164,31 @@ def test_sharded_degree2_on_one_gpu(tmp_path, world, backend, log_n, gather_log)
     for r in range(world):
         d = np.load(tmp_path / f"q{r}.npz")
         assert np.array_equal(d["coeffs"], oc) and np.array_equal(d["ch"], och), f"rank {r}"
+
+
+# ---------------------------------------------------------------- a context that owns its stream
+@pytest.mark.parametrize("gather_log", [None, 6, 13])
+def test_sharded_loops_on_a_context_with_its_own_stream(gather_log):
+    """DeviceShard / DeviceShard4 on a plain Context (its own non-blocking stream, not torch's current one): the
+    gathers and D2H copies of zk_amd.sharded run on torch's stream, so the shards order the two themselves."""
+    ctx = zk_amd.Context(0)
+    assert ctx.stream != torch.cuda.current_stream().cuda_stream
+    for log_n in (9, 15):
+        table = O.gen_table(SEED + log_n, 0, 1 << log_n)
+        local = zk_amd.MultiLinearPolynomial(table, ctx=ctx)
+        sh = sharded.DeviceShard(local)
+        tr = zk_amd.Transcript()
+        tr.append(local.to_bytes())
+        claim, coeffs, ch = sharded.generate_round_polys_sharded(sh, tr, 1, None, None, None, gather_log)
+        sh.close()
+        oclaim, ocoeffs, och = O.sumcheck_prove(table)
+        assert list(claim) == list(oclaim) and np.array_equal(coeffs, ocoeffs) and np.array_equal(ch, och)
+    for log_n in (6, 12):
+        tabs = [O.gen_table(SEED + 50 + k, 0, 1 << log_n) for k in range(4)]
+        m = [zk_amd.MultiLinearPolynomial(t, ctx=ctx) for t in tabs]
+        sh4 = sharded.DeviceShard4(m)
+        tr, otr = zk_amd.Transcript(), O.OTranscript()
+        coeffs, ch = sharded.generate_round_polys_sum2x2_sharded(sh4, tr, 1, None, None, gather_log)
+        sh4.close()
+        ocoeffs, och = O.sumcheck_prove_sum([[tabs[0], tabs[1]], [tabs[2], tabs[3]]], O.fq1(0), otr)
+        assert np.array_equal(coeffs, ocoeffs) and np.array_equal(ch, och) and tr.peek_digest() == otr.peek_digest()

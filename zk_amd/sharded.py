@@ -70,6 +70,13 @@ class DeviceShard:
         h = C.c_void_p()
         check(lib().zk_shard_begin(self.ctx.h, local.h, C.byref(h)), self.ctx.h)
         self.h = h
+        self._foreign = _foreign_stream(self.ctx)
+
+    def _order(self) -> None:
+        """The gathers and D2H copies of this module run on torch's current stream.  A context created on that stream
+        (torch_stream_context) orders with them by itself; one that owns its stream is synchronized after every enqueue."""
+        if self._foreign:
+            self.ctx.synchronize()
 
     def vars_left(self) -> int:
         return lib().zk_shard_vars_left(self.h)
@@ -83,17 +90,22 @@ class DeviceShard:
         return self._torch.empty((count, 4), dtype=self._torch.int64, device=self._torch.device("cuda", self.ctx.device_id))
 
     def block_sums(self, m: int, out) -> None:
+        _wait_torch(self)
         check(lib().zk_shard_block_sums(self.h, m, C.c_void_p(out.data_ptr())), self.ctx.h)
+        self._order()
 
     def fold(self, m: int, r: np.ndarray, m_next: int, out) -> None:
         r = np.ascontiguousarray(r, dtype=np.uint64)
+        _wait_torch(self)
         check(lib().zk_shard_fold(self.h, m, _ptr(r), m_next, C.c_void_p(out.data_ptr())), self.ctx.h)
+        self._order()
 
     def table(self):
         """The current local table as a (2^vars_left, 4) int64 device tensor (a copy, on the context stream)."""
         out = self._torch.empty((1 << self.vars_left(), 4), dtype=self._torch.int64,
                                 device=self._torch.device("cuda", self.ctx.device_id))
         check(lib().zk_shard_copy_table(self.h, C.c_void_p(out.data_ptr())), self.ctx.h)
+        self._order()
         return out
 
     def finish(self, table, transcript: Transcript):
@@ -101,6 +113,7 @@ class DeviceShard:
         from .sumcheck import SumcheckProver
 
         table = table.contiguous()
+        _wait_torch(self)  # the gathered table was produced on torch's stream
         poly = MultiLinearPolynomial.wrap_device(table.data_ptr(), table.shape[0], ctx=self.ctx)
         return SumcheckProver.generate_round_polys(poly, transcript)
 
@@ -114,6 +127,20 @@ class DeviceShard:
             self.close()
         except Exception:
             pass
+
+
+def _foreign_stream(ctx: Context) -> bool:
+    """True when the context's kernels do not run on torch's current stream of its device."""
+    import torch
+
+    return ctx.stream != torch.cuda.current_stream(torch.device("cuda", ctx.device_id)).cuda_stream
+
+
+def _wait_torch(shard) -> None:
+    """Work torch enqueued on its stream (a gathered table, a freshly allocated buffer's producer) before a context that
+    owns its stream reads or overwrites it."""
+    if shard._foreign:
+        shard._torch.cuda.current_stream(shard._torch.device("cuda", shard.ctx.device_id)).synchronize()
 
 
 _pinned = {}
@@ -285,6 +312,11 @@ class DeviceShard4:
         h = C.c_void_p()
         check(lib().zk_shard4_begin(self.ctx.h, arr, C.byref(h)), self.ctx.h)
         self.h = h
+        self._foreign = _foreign_stream(self.ctx)
+
+    def _order(self) -> None:  # as DeviceShard._order
+        if self._foreign:
+            self.ctx.synchronize()
 
     def local_len(self) -> int:
         return lib().zk_shard4_len(self.h)
@@ -293,28 +325,37 @@ class DeviceShard4:
         return self._torch.empty((4, 4), dtype=self._torch.int64, device=self._torch.device("cuda", self.ctx.device_id))
 
     def eval(self, out) -> None:
+        _wait_torch(self)
         check(lib().zk_shard4_eval(self.h, C.c_void_p(out.data_ptr())), self.ctx.h)
+        self._order()
 
     def fold(self, r: np.ndarray, out) -> None:
         r = np.ascontiguousarray(r, dtype=np.uint64)
+        _wait_torch(self)
         check(lib().zk_shard4_fold(self.h, _ptr(r), C.c_void_p(out.data_ptr())), self.ctx.h)
+        self._order()
 
     # two rounds per exchange
     def new_buf9(self):
         return self._torch.empty((9, 4), dtype=self._torch.int64, device=self._torch.device("cuda", self.ctx.device_id))
 
     def sum9(self, out) -> None:
+        _wait_torch(self)
         check(lib().zk_shard4_sum9(self.h, C.c_void_p(out.data_ptr())), self.ctx.h)
+        self._order()
 
     def fold2(self, r2: np.ndarray, out) -> None:
         r2 = np.ascontiguousarray(r2, dtype=np.uint64)
+        _wait_torch(self)
         check(lib().zk_shard4_fold2(self.h, _ptr(r2), C.c_void_p(out.data_ptr()) if out is not None else None), self.ctx.h)
+        self._order()
 
     def tables_tensor(self):
         """The four current local tables as one (4, len, 4) int64 device tensor (a copy, on the context stream)."""
         out = self._torch.empty((4, self.local_len(), 4), dtype=self._torch.int64,
                                 device=self._torch.device("cuda", self.ctx.device_id))
         check(lib().zk_shard4_copy_tables(self.h, C.c_void_p(out.data_ptr())), self.ctx.h)
+        self._order()
         return out
 
     def finish(self, tables, transcript: Transcript):
@@ -323,6 +364,7 @@ class DeviceShard4:
         from .sumcheck import SumcheckProver
 
         tables = tables.contiguous()
+        _wait_torch(self)
         t = [MultiLinearPolynomial.wrap_device(tables[k].data_ptr(), tables.shape[1], ctx=self.ctx) for k in range(4)]
         f = SumPolynomial([ProductPolynomial(t[:2]), ProductPolynomial(t[2:])])
         proof, ch = SumcheckProver.generate_proof_for_partial_verify(np.zeros(4, dtype=np.uint64), f, transcript)
