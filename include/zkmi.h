@@ -219,6 +219,38 @@ int zk_shard4_copy_tables(zk_shard4 *s, void *dst_dev);
 int zk_sumcheck_prove_sum2x2_host(zk_transcript *t, const uint64_t *tables, size_t len, uint64_t *coeffs_out,
                                   uint64_t *challenges_out);
 
+/* ---- sharded provers: the loops above inside the library, the exchange included --------------------------------
+ * One process per GPU.  A context becomes rank `rank` of `world` (a power of two) by one of
+ *   zk_comm_init_rccl: RCCL over xGMI.  One rank calls zk_comm_unique_id and hands the 128 bytes to the others by any
+ *     means it has (the launcher's rendezvous, a file, MPI); every rank then calls zk_comm_init_rccl (collective:
+ *     ncclCommInitRank).  The all-gathers run on the context's stream (ncclAllGather).  librccl.so.1 is loaded on
+ *     first use -- the copy already in the process if the host framework loaded one -- so single-GPU users never map it.
+ *   zk_comm_init_host: the caller's own all-gather over HOST buffers (MPI_Allgather shaped: every rank's `bytes` at
+ *     send -> recv[world][bytes], rank order; return 0 on success).  The library stages through pinned memory.
+ * Failures of either come back as ZK_E_COMM with the text in zk_last_error.  The reference has no counterpart
+ * (single thread); what stays identical is generate_round_polys (sumcheck/src/prover.rs:45-155):
+ * every rank returns the same claim, coefficients and challenges as the unsharded prover on the whole table.
+ *   local / tables: this rank's shard(s) (zk_mle_upload_mont_shard / zk_mle_generate_strided: local entry j =
+ *     global entry j * world + rank)
+ *   gather_log: local tables of at most 2^gather_log entries are all-gathered and every rank finishes alone
+ *     (replicated, no further exchange; recommended: 13); negative: sharded to the end
+ *   zk_sumcheck_prove_mle_sharded: absorb_table / transcript as zk_sumcheck_prove_mle (the absorbed byte stream is
+ *     the WHOLE table's to_bytes(), gathered chunk by chunk); coeffs_out (log2(len) + log2(world)) x 2
+ *   zk_sumcheck_prove_sum2x2_sharded: as zk_sumcheck_prove_sum2x2; coeffs_out (log2(len) + log2(world)) x 3 */
+#define ZK_COMM_ID_BYTES 128
+typedef int (*zk_allgather_host_fn)(void *user, const void *send, void *recv, size_t bytes_per_rank);
+int zk_comm_unique_id(uint8_t out[ZK_COMM_ID_BYTES]);
+int zk_comm_init_rccl(zk_ctx *ctx, const uint8_t id[ZK_COMM_ID_BYTES], int rank, int world);
+int zk_comm_init_host(zk_ctx *ctx, int rank, int world, zk_allgather_host_fn fn, void *user);
+void zk_comm_destroy(zk_ctx *ctx); /* also done by zk_ctx_destroy */
+int zk_comm_rank(const zk_ctx *ctx);  /* -1 without a communicator */
+int zk_comm_world(const zk_ctx *ctx); /* 0 without a communicator */
+int zk_sumcheck_prove_mle_sharded(zk_ctx *ctx, const zk_mle *local, int absorb_table, zk_transcript *transcript,
+                                  int gather_log, uint64_t claim_out[4], uint64_t *coeffs_out, uint64_t *challenges_out);
+int zk_sumcheck_prove_sum2x2_sharded(zk_ctx *ctx, zk_mle *const tables[4], const uint64_t claim_mont[4],
+                                     zk_transcript *transcript, int gather_log, uint64_t *coeffs_out,
+                                     uint64_t *challenges_out);
+
 /* ---- sumcheck verifier (sumcheck/src/verifier.rs) -- the parity harness ---------------- */
 /* partial_verify :29-62 (host only). */
 int zk_sumcheck_partial_verify(const uint64_t claim_mont[4], const uint64_t *coeffs, size_t n_rounds,

@@ -192,3 +192,91 @@ def test_sharded_loops_on_a_context_with_its_own_stream(gather_log):
         sh4.close()
         ocoeffs, och = O.sumcheck_prove_sum([[tabs[0], tabs[1]], [tabs[2], tabs[3]]], O.fq1(0), otr)
         assert np.array_equal(coeffs, ocoeffs) and np.array_equal(ch, och) and tr.peek_digest() == otr.peek_digest()
+
+
+# ---------------------------------------------------------------- the loops inside the library (sharded.cpp)
+def _worker_lib(rank, world, port, backend, transport, log_n, gather_log, absorb, knobs, outdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    try:
+        ctx = zk_amd.Context(0)  # its own stream: the library orders its kernels, copies and collectives itself
+        if knobs:
+            ctx.set_wide_fold(8, 2, 10)
+            ctx.set_dma_gates(0, 0, 0)
+        assert sharded.comm_init(ctx, dist, None, transport) == transport
+        assert zk_amd.lib().zk_comm_rank(ctx.h) == rank and zk_amd.lib().zk_comm_world(ctx.h) == world
+        n = 1 << log_n
+        local = zk_amd.MultiLinearPolynomial.generate(SEED, n // world, first=rank, step=world, ctx=ctx)
+        if absorb:      # generate_sumcheck_proof: fresh transcript, the WHOLE table's bytes absorbed (gathered chunk by chunk)
+            claim, coeffs, ch = sharded.prove_mle_sharded(local, None, True, gather_log)
+        else:
+            tr = zk_amd.Transcript()
+            tr.append(O.mle_to_bytes(O.gen_table(SEED, 0, n)))
+            claim, coeffs, ch = sharded.prove_mle_sharded(local, tr, False, gather_log)
+        tabs = [zk_amd.MultiLinearPolynomial.generate(SEED + 10 + k, n // world, first=rank, step=world, ctx=ctx) for k in range(4)]
+        tr2 = zk_amd.Transcript()
+        tr2.append(b"degree-2 sharded")
+        c2, ch2 = sharded.prove_sum2x2_sharded(tabs, tr2, None, gather_log)
+        np.savez(os.path.join(outdir, f"L{rank}.npz"), claim=claim, coeffs=coeffs, ch=ch, c2=c2, ch2=ch2, dg=np.frombuffer(tr2.peek_digest(), dtype=np.uint8))
+        sharded.comm_destroy(ctx)
+        assert zk_amd.lib().zk_comm_world(ctx.h) == 0
+    finally:
+        dist.destroy_process_group()
+
+
+def _check_lib(tmp_path, world, log_n):
+    table = O.gen_table(SEED, 0, 1 << log_n)
+    oclaim, ocoeffs, och = O.sumcheck_prove(table)
+    tabs = [O.gen_table(SEED + 10 + k, 0, 1 << log_n) for k in range(4)]
+    otr = O.OTranscript()
+    otr.append(b"degree-2 sharded")
+    oc2, och2 = O.sumcheck_prove_sum([[tabs[0], tabs[1]], [tabs[2], tabs[3]]], O.fq1(0), otr)
+    for r in range(world):
+        d = np.load(tmp_path / f"L{r}.npz")
+        assert np.array_equal(d["claim"], oclaim), f"rank {r}: claim"
+        assert np.array_equal(d["coeffs"], ocoeffs), f"rank {r}: round polynomials"
+        assert np.array_equal(d["ch"], och), f"rank {r}: challenges"
+        assert np.array_equal(d["c2"], oc2) and np.array_equal(d["ch2"], och2), f"rank {r}: degree 2"
+        assert d["dg"].tobytes() == otr.peek_digest(), f"rank {r}: transcript state"
+
+
+@pytest.mark.parametrize("world,log_n,gather_log,absorb,knobs", [
+    (2, 14, 13, True, False), (4, 13, 6, False, False), (8, 12, None, True, False), (2, 3, None, False, False), (2, 15, 9, False, True),
+    (4, 14, None, False, True), (2, 12, 1, False, False), (8, 9, 13, True, False), (2, 1, None, False, False), (4, 2, 0, False, False)])
+def test_library_sharded_provers_ranks_on_one_gpu(tmp_path, world, log_n, gather_log, absorb, knobs):
+    """zk_sumcheck_prove_mle_sharded / _sum2x2_sharded (the loops in C++, exchange through the library's host all-gather
+    callback, here over gloo: RCCL refuses several ranks on one GPU) against the oracle's proof of the unsharded table."""
+    mp.spawn(_worker_lib, args=(world, _free_port(), "gloo", "host", log_n, gather_log, absorb, knobs, str(tmp_path)), nprocs=world, join=True)
+    _check_lib(tmp_path, world, log_n)
+
+
+@pytest.mark.parametrize("log_n,gather_log,absorb", [(12, 7, True), (13, None, False), (10, 13, False)])
+def test_library_sharded_provers_single_rank_rccl(tmp_path, log_n, gather_log, absorb):
+    """the RCCL transport (ncclCommInitRank + ncclAllGather inside libzkmi.so) with the one rank a test box can hold"""
+    mp.spawn(_worker_lib, args=(1, _free_port(), "nccl", "rccl", log_n, gather_log, absorb, False, str(tmp_path)), nprocs=1, join=True)
+    _check_lib(tmp_path, 1, log_n)
+
+
+def test_library_sharded_prover_without_transport_and_errors():
+    ctx = zk_amd.Context(0)
+    L = zk_amd.lib()
+    table = O.gen_table(SEED, 0, 1 << 10)
+    local = zk_amd.MultiLinearPolynomial(table, ctx=ctx)
+    with pytest.raises(RuntimeError):
+        sharded.prove_mle_sharded(local)            # no communicator yet
+    claim = np.empty(4, dtype=np.uint64)
+    coeffs = np.empty((10, 2, 4), dtype=np.uint64)
+    rc = L.zk_sumcheck_prove_mle_sharded(ctx.h, local.h, 1, None, 13, claim.ctypes.data_as(zk_amd._lib.u64p), coeffs.ctypes.data_as(zk_amd._lib.u64p), None)
+    assert rc == 10 and b"communicator" in L.zk_last_error(ctx.h)   # ZK_E_COMM
+    assert L.zk_comm_init_host(ctx.h, 0, 3, None, None) == 8        # not a power of two / no callback
+    assert L.zk_comm_init_host(ctx.h, 0, 1, None, None) == 0        # a single rank that exchanges nothing
+    assert L.zk_comm_init_host(ctx.h, 0, 1, None, None) == 10       # one communicator per context
+    for gather_log in (None, 4, 13):
+        c, co, ch = sharded.prove_mle_sharded(local, None, True, gather_log)
+        oclaim, ocoeffs, och = O.sumcheck_prove(table)
+        assert list(c) == list(oclaim) and np.array_equal(co, ocoeffs) and np.array_equal(ch, och)
+    sharded.comm_destroy(ctx)

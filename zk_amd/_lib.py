@@ -83,6 +83,14 @@ SYMBOLS = [
     ("zk_shard4_copy_tables", C.c_int, [_VP, _VP]),
     ("zk_sumcheck_round_from_evals", C.c_int, [_VP, u64p, C.c_int, u64p, u64p]),
     ("zk_sumcheck_prove_sum2x2_host", C.c_int, [_VP, u64p, C.c_size_t, u64p, u64p]),
+    ("zk_comm_unique_id", C.c_int, [u8p]),
+    ("zk_comm_init_rccl", C.c_int, [_VP, u8p, C.c_int, C.c_int]),
+    ("zk_comm_init_host", C.c_int, [_VP, C.c_int, C.c_int, _VP, _VP]),
+    ("zk_comm_destroy", None, [_VP]),
+    ("zk_comm_rank", C.c_int, [_VP]),
+    ("zk_comm_world", C.c_int, [_VP]),
+    ("zk_sumcheck_prove_mle_sharded", C.c_int, [_VP, _VP, C.c_int, _VP, C.c_int, u64p, u64p, u64p]),
+    ("zk_sumcheck_prove_sum2x2_sharded", C.c_int, [_VP, C.POINTER(_VP), u64p, _VP, C.c_int, u64p, u64p]),
     ("zk_sumcheck_partial_verify", C.c_int, [u64p, u64p, C.c_size_t, C.c_size_t, _VP, C.POINTER(C.c_int), u64p, u64p]),
     ("zk_sumcheck_verify_mle", C.c_int, [_VP, _VP, u64p, u64p, C.c_size_t, C.POINTER(C.c_int)]),
     ("zk_mle_w_add", C.c_int, [_VP, _VP, C.POINTER(_VP)]),

@@ -78,6 +78,9 @@ void launch_fold2_tables(const void* const s[4], void* const d[4], size_t outlen
                          const DmaGates& gates = DmaGates());
 // out[k*n + i] = t[k][i], k < 4, i < n
 void launch_gather4(const void* const t[4], size_t n, void* out, hipStream_t st);
+// out[(t * L + j) * world + q] = in[(q * ntab + t) * L + j]: the ranks' gathered local tables (rank-major) -> the remaining
+// tables, entry j * world + q = rank q's entry j (the table is sharded on its LOW index bits)
+void launch_interleave(const void* in, void* out, int world, int ntab, size_t L, hipStream_t st);
 void launch_from_le32(const void* in, void* out, size_t n, hipStream_t st);
 void launch_to_le32(const void* in, void* out, size_t n, hipStream_t st);
 void launch_generate(void* out, uint64_t seed, uint64_t first, uint64_t step, size_t n, hipStream_t st);

@@ -965,6 +965,16 @@ __global__ void __launch_bounds__(kThreads) k_gather4(Tab4 T, size_t n, fq* __re
     if (i < 4 * n) fq_store(out + i, fq_load(T.t[i / n] + i % n));
 }
 
+// the switch from sharded to replicated passes: gathered local tables (rank-major) -> the remaining tables
+__global__ void __launch_bounds__(kThreads) k_interleave(const fq* __restrict__ in, fq* __restrict__ out, unsigned world, unsigned ntab, size_t L) {
+    const size_t total = (size_t)world * ntab * L, stride = (size_t)gridDim.x * kThreads;
+    for (size_t o = (size_t)blockIdx.x * kThreads + threadIdx.x; o < total; o += stride) {
+        const unsigned q = (unsigned)(o % world);
+        const size_t tj = o / world; // t * L + j
+        fq_store(out + o, fq_load(in + (size_t)q * ntab * L + tj));
+    }
+}
+
 // ---- format conversion / generation ------------------------------------------------------
 // canonical little-endian 256-bit values (any value < 2^256) -> Montgomery table
 __global__ void __launch_bounds__(kThreads) k_from_le32(const fq* __restrict__ in, fq* __restrict__ out, size_t n) {
@@ -1278,6 +1288,10 @@ void launch_fold2_tables(const void* const s[4], void* const d[4], size_t outlen
     if (gx > (size_t)kMaxBlocks) gx = kMaxBlocks;
     g_forms |= kFormFold2Reg;
     hipLaunchKernelGGL(k_fold2_tables, dim3((unsigned)gx, 4), dim3(kThreads), 0, st, S, D, outlen, W);
+}
+void launch_interleave(const void* in, void* out, int world, int ntab, size_t L, hipStream_t st) {
+    hipLaunchKernelGGL(k_interleave, dim3(grid_for((size_t)world * ntab * L)), dim3(kThreads), 0, st, (const fq*)in, (fq*)out, (unsigned)world,
+                       (unsigned)ntab, L);
 }
 void launch_from_le32(const void* in, void* out, size_t n, hipStream_t st) {
     hipLaunchKernelGGL(k_from_le32, dim3(grid_for(n)), dim3(kThreads), 0, st, (const fq*)in, (fq*)out, n);

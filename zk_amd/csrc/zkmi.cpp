@@ -82,6 +82,7 @@ void zk_ctx_destroy(zk_ctx* c) {
     if (c->work[1]) (void)hipFree(c->work[1]);
     if (c->stage) (void)hipFree(c->stage);
     if (c->gkr_scratch) (void)hipFree(c->gkr_scratch);
+    zk_comm_destroy(c);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -379,7 +380,8 @@ int zk_mle_round_sums(const zk_mle* m, uint64_t out[8]) {
 // gathered [world][2^m] array.  folded_out[q] (optional) = rank q's block sums folded at the m
 // challenges: when the local tables are down to 2^m entries these are the entries of the remaining
 // g-variable table, index q.
-namespace {
+} // extern "C"
+namespace zki {
 void host_rounds(zk_transcript* tr, const uint64_t* sums, int world, unsigned m, uint64_t* coeffs_out, uint64_t* ch_out,
                  uint64_t* folded_out, uint64_t* total_out) {
     const unsigned nb = 1u << m;
@@ -435,7 +437,8 @@ int fold_pass(const zk_ctx& k, const uint64_t two24[4], const void* src, void* d
     }
     return zkk::launch_multifold(m, src, dst, lout, r_mont, m_next, k.double_buffer, partials, sums, stream);
 }
-} // namespace
+} // namespace zki
+extern "C" {
 
 
 int zk_sumcheck_rounds_from_block_sums(zk_transcript* t, const uint64_t* sums, int world, int m, uint64_t* coeffs_out,
@@ -561,15 +564,21 @@ int zk_sumcheck_prove_mle(zk_ctx* c, const zk_mle* poly, int absorb_table, zk_tr
         rc = stream_le32(c, poly->d, len, [&](const uint8_t* p, size_t nbytes, size_t) { tr->append(p, nbytes); });
         if (rc) return rc;
     }
+    return prove_mle_dev(c, poly->d, n, tr, claim_out, coeffs_out, challenges_out);
+}
+} // extern "C"
 
+// generate_round_polys (prover.rs:45-155, MLE branch) on a device table of 2^n entries and the caller's transcript
+int zki::prove_mle_dev(zk_ctx* c, const void* table, unsigned n, zk_transcript* tr, uint64_t claim_out[4], uint64_t* coeffs_out,
+                       uint64_t* challenges_out) {
     if (n == 0) { // zero variables: no rounds; initial_claim_sum = the single entry
-        HIPCHK(c, hipMemcpyAsync(c->sums_host, poly->d, kElem, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->sums_host, table, kElem, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         std::memcpy(claim_out, c->sums_host, kElem);
         return ZK_OK;
     }
-
-    zk_shard st{c, poly->d, n, 0};
+    int rc;
+    zk_shard st{c, table, n, 0};
     unsigned m = next_batch(c, st.ell), k = 0;
     if ((rc = zk_shard_block_sums(&st, (int)m, c->sums_host_dev))) return rc; // sums land in pinned host memory
     for (;;) {
@@ -588,7 +597,6 @@ int zk_sumcheck_prove_mle(zk_ctx* c, const zk_mle* poly, int absorb_table, zk_tr
 }
 
 // ---- sumcheck prover: Sum[Prod[t0,t1], Prod[t2,t3]] ---------------------------------------------
-} // extern "C"
 
 namespace {
 // one round of the SumPolynomial branch from the three evaluations (prover.rs:102-107, :126-135);
@@ -824,12 +832,6 @@ int zk_sumcheck_prove_sum2x2(zk_ctx* c, zk_mle* const tables[4], const uint64_t 
 }
 
 // ---- degree-2 prover in steps (sharded tables) ---------------------------------------------------
-struct zk_shard4 {
-    zk_ctx* ctx;
-    const void* cur[4];
-    size_t len; // entries per table
-    int pass;
-};
 
 // evals: [world][3] partial evaluations (every rank's share of ev[0..3)); sums them, runs the round
 int zk_sumcheck_round_from_evals(zk_transcript* t, const uint64_t* evals, int world, uint64_t coeffs_out[12], uint64_t challenge_out[4]) {

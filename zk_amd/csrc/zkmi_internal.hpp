@@ -52,6 +52,8 @@ struct zk_transcript {
     }
 };
 
+struct zk_comm; // sharded.cpp: the exchange between the ranks of a sharded prove
+
 struct ProfSlot { int kernel; hipEvent_t a, b; uint64_t bytes; };
 
 struct zk_ctx {
@@ -76,6 +78,7 @@ struct zk_ctx {
     bool deg2_pairs = true;      // degree-2 prover: two rounds per device pass (k_sum9 / k_fold2x4_sum9)
     int lazy_group = 4;          // elements per register load buffer in k_multifold_lazy (2 or 4)
     zkk::DmaGates gates;         // size thresholds of the LDS-DMA forms (zk_ctx_set_dma_gates)
+    zk_comm* comm = nullptr;     // zk_comm_init_*: this context is rank `comm->rank` of a sharded prove
     void* work[2] = {nullptr, nullptr};
     size_t work_cap[2] = {0, 0}; // bytes
     void* stage = nullptr;       // kChunkElems elements
@@ -103,6 +106,14 @@ struct zk_shard {
     zk_ctx* ctx;
     const void* cur; // current local table
     unsigned ell;    // variables left in it
+    int pass;
+};
+
+// four factor tables being folded from the top (degree-2 branch in steps)
+struct zk_shard4 {
+    zk_ctx* ctx;
+    const void* cur[4];
+    size_t len; // entries per table
     int pass;
 };
 
@@ -265,6 +276,13 @@ int stream_le32(zk_ctx* c, const void* table, size_t len, Sink&& sink) {
 }
 
 // defined in zkmi.cpp
+// m rounds of the MLE branch on the gathered [world][2^m] block sums (see zkmi.cpp)
+void host_rounds(zk_transcript* tr, const uint64_t* sums, int world, unsigned m, uint64_t* coeffs_out, uint64_t* ch_out, uint64_t* folded_out,
+                 uint64_t* total_out);
+int fold_pass(const zk_ctx& k, const uint64_t two24[4], const void* src, void* dst, size_t lout, int m, const uint64_t* r_mont, int m_next,
+              void* partials, void* wide_w, void* sums, hipStream_t stream);
+int prove_mle_dev(zk_ctx* c, const void* table, unsigned n, zk_transcript* tr, uint64_t claim_out[4], uint64_t* coeffs_out,
+                  uint64_t* challenges_out);
 int prove_sum2x2_dev(zk_ctx* c, const void* const tables[4], size_t len, zk_transcript* tr, uint64_t* coeffs_out,
                      uint64_t* challenges_out, uint64_t* final_out);
 

@@ -472,3 +472,99 @@ def generate_round_polys_sum2x2_sharded(shard4, transcript: Transcript, world: i
         c, r = prove_sum2x2_host(transcript, rows.transpose(1, 0, 2))
         coeffs[ell:], ch[ell:] = c, r
     return coeffs, ch
+
+
+# ---------------------------------------------------------------- the same loops INSIDE the library (sharded.cpp)
+# zk_sumcheck_prove_mle_sharded / zk_sumcheck_prove_sum2x2_sharded run the loops above in C++ with the exchange done by
+# the library itself: RCCL (ncclAllGather on the context stream) or a host all-gather callback.  Python only hands over
+# the unique id (or the callback); a Rust caller does the same through the C ABI and needs no torch.
+_HOST_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
+
+
+def comm_init(ctx: Context, dist=None, group=None, transport: str | None = None) -> str:
+    """Make `ctx` this process's rank of the in-library sharded provers.  `dist`: an initialised torch.distributed
+    (None: a single rank).  transport "rccl": rank 0's ncclUniqueId is broadcast through `dist`, every rank joins an
+    RCCL communicator owned by the library (default with the nccl backend, and for a single rank); "host": the
+    library's host all-gather callback goes through `dist` on CPU tensors (default with gloo).  Returns the transport."""
+    import torch
+
+    world = dist.get_world_size(group) if dist is not None else 1
+    rank = dist.get_rank(group) if dist is not None else 0
+    backend = dist.get_backend(group) if dist is not None else None
+    if transport is None:
+        transport = "rccl" if backend in (None, "nccl") else "host"
+    if transport == "rccl":
+        ident = np.zeros(128, dtype=np.uint8)
+        if rank == 0:
+            check(lib().zk_comm_unique_id(ident.ctypes.data_as(C.POINTER(C.c_uint8))), ctx.h)
+        if world > 1:
+            dev = torch.device("cuda", ctx.device_id) if backend == "nccl" else torch.device("cpu")
+            t = torch.from_numpy(ident).to(dev)
+            dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            ident = t.cpu().numpy()
+        check(lib().zk_comm_init_rccl(ctx.h, ident.ctypes.data_as(C.POINTER(C.c_uint8)), rank, world), ctx.h)
+    elif transport == "host":
+        if backend == "nccl":
+            raise ValueError("the host transport needs a backend that gathers CPU tensors (gloo)")
+
+        def gather(_user, send, recv, nbytes):
+            try:
+                src = torch.from_numpy(np.ctypeslib.as_array((C.c_uint8 * nbytes).from_address(send))).clone()
+                dst = torch.from_numpy(np.ctypeslib.as_array((C.c_uint8 * (nbytes * world)).from_address(recv)))
+                if world == 1:
+                    dst.copy_(src)
+                else:
+                    dist.all_gather(list(dst.view(world, nbytes).unbind(0)), src, group=group)
+                return 0
+            except Exception as e:  # an exception must not unwind through the C caller
+                import sys
+                print(f"zk_amd.sharded: host all-gather failed: {e!r}", file=sys.stderr)
+                return 1
+
+        cb = _HOST_FN(gather)
+        ctx._comm_cb = cb  # the library keeps the pointer: keep the object alive as long as the context
+        check(lib().zk_comm_init_host(ctx.h, rank, world, C.cast(cb, C.c_void_p), None), ctx.h)
+    else:
+        raise ValueError("transport: 'rccl' or 'host'")
+    return transport
+
+
+def comm_destroy(ctx: Context) -> None:
+    lib().zk_comm_destroy(ctx.h)
+    ctx._comm_cb = None
+
+
+def _gather_arg(gather_log):
+    return -1 if gather_log is None else int(gather_log)
+
+
+def prove_mle_sharded(local: MultiLinearPolynomial, transcript: Transcript | None = None, absorb_table: bool = False,
+                      gather_log: int | None = DEFAULT_GATHER_LOG):
+    """zk_sumcheck_prove_mle_sharded on this rank's shard: (claim (4,), round_polys (n,2,4), challenges (n,4)), the same on
+    every rank.  transcript None = generate_sumcheck_proof (fresh transcript + absorb of the whole table's bytes)."""
+    ctx = local.ctx
+    world = lib().zk_comm_world(ctx.h)
+    if world < 1:
+        raise RuntimeError("comm_init(ctx, ...) first")
+    n = len(local).bit_length() - 1 + world.bit_length() - 1
+    claim = np.empty(4, dtype=np.uint64)
+    coeffs = np.empty((max(n, 1), 2, 4), dtype=np.uint64)
+    ch = np.empty((max(n, 1), 4), dtype=np.uint64)
+    check(lib().zk_sumcheck_prove_mle_sharded(ctx.h, local.h, int(absorb_table), transcript.h if transcript is not None else None,
+                                              _gather_arg(gather_log), _ptr(claim), _ptr(coeffs), _ptr(ch)), ctx.h)
+    return claim, coeffs[:n], ch[:n]
+
+
+def prove_sum2x2_sharded(tables, transcript: Transcript, claim=None, gather_log: int | None = DEFAULT_GATHER_LOG):
+    """zk_sumcheck_prove_sum2x2_sharded on this rank's shards of the four factor tables: (round_polys (n,3,4), challenges (n,4))."""
+    ctx = tables[0].ctx
+    world = lib().zk_comm_world(ctx.h)
+    if world < 1:
+        raise RuntimeError("comm_init(ctx, ...) first")
+    n = len(tables[0]).bit_length() - 1 + world.bit_length() - 1
+    claim = np.zeros(4, dtype=np.uint64) if claim is None else np.ascontiguousarray(claim, dtype=np.uint64)
+    coeffs = np.empty((max(n, 1), 3, 4), dtype=np.uint64)
+    ch = np.empty((max(n, 1), 4), dtype=np.uint64)
+    arr = (C.c_void_p * 4)(*[t.h for t in tables])
+    check(lib().zk_sumcheck_prove_sum2x2_sharded(ctx.h, arr, _ptr(claim), transcript.h, _gather_arg(gather_log), _ptr(coeffs), _ptr(ch)), ctx.h)
+    return coeffs[:n], ch[:n]
