@@ -2,13 +2,16 @@
 """bench.py -- sumcheck prove time / field elements per second on MI355X.
 
   python bench.py --gpus 1 --steps K --warmup W          (single GPU)
-  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (one rank per GPU)
+  python bench.py --gpus N ...                           (starts its own N ranks, one per GPU, before touching a GPU)
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (one rank per GPU, the driver's form)
 
 A "step" is one complete run of the prover's round loop (sumcheck/src/prover.rs:45-155) over a
 synthetic, device-resident 2^log_n-entry BN254-Fq table: n rounds of
 {reduce -> host Keccak/challenge -> fold}.  The table absorb into Keccak (32*N bytes through a
 serial sponge) happens once, OUTSIDE the timed region, and is reported separately
-(`absorb_ms`); `value` is table entries / round-loop time.  Prints ONE JSON line on rank 0.
+(`absorb_ms`); `value` is table entries / round-loop time.  Prints ONE JSON line on rank 0; with one
+GPU the same line also carries the other workloads north_star names (`extra`: a 2^20..2^30 size sweep,
+the degree-2 4 x 2^26 prove and the GKR config-5 prove).
 """
 from __future__ import annotations
 
@@ -16,6 +19,8 @@ import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -24,9 +29,12 @@ sys.path.insert(0, ROOT)
 
 SEED = 0x5EED0000
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+METRIC = "sumcheck prove ms + field elems/s at 2^28-entry MLE, 1/8 GPUs; % HBM roofline"
+DTYPE = "u32x8 (254-bit Montgomery, BN254 Fq)"
+KERNEL_NAMES = ("block_sums", "multifold_wide", "multifold", "multifold_tail", "eval3", "fold4_eval3", "sum9", "fold2x4_sum9")
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -37,6 +45,7 @@ def parse():
     ap.add_argument("--gkr-log-width", type=int, default=20, help="gates per layer = 2^k (BASELINE config 5: depth 16, k = 20)")
     ap.add_argument("--no-absorb", action="store_true", help="skip the one-off 32*N-byte Keccak table absorb")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra workloads (size sweep, degree 2, GKR) of the single-GPU line")
     ap.add_argument("--cpu-log-n", type=int, default=24, help="bounded CPU sample size (2^k entries)")
     ap.add_argument("--fold-batch", type=int, default=0, help="rounds bound per device pass (0 = library default)")
     ap.add_argument("--wide-batch", type=int, default=-1, help="rounds bound by a pass over a large table (5..8, 0 = off, -1 = library default 8)")
@@ -49,12 +58,43 @@ def parse():
     ap.add_argument("--gather-log", type=int, default=13, help="multi-GPU: local tables of <= 2^k entries are all-gathered and finished on every rank (-1 = sharded to the end)")
     ap.add_argument("--deg2-lazy-from", type=int, default=None, help="degree-2 prover: unreduced nine-sum accumulation from 2^k quarter-entries (negative = never)")
     ap.add_argument("--weak", action="store_true", help="multi-GPU: 2^log_n entries PER GPU instead of in total")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for the multi-GPU exchange")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend of the ranks' rendezvous (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--shared-device", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
-    ap.add_argument("--force-sharded", action="store_true", help="run the multi-GPU code path (torch.distributed exchange) even with one rank")
-    return ap.parse_args()
+    ap.add_argument("--force-sharded", action="store_true", help="run the multi-GPU code path even with one rank")
+    ap.add_argument("--sharded-impl", choices=["lib", "py"], default="lib",
+                    help="multi-GPU loop: inside libzkmi.so (RCCL or host all-gather, default) or zk_amd/sharded.py over torch.distributed")
+    return ap.parse_args(argv)
 
 
+# ------------------------------------------------------------------------------------------------ launcher
+def launch_ranks(args) -> int:
+    """`--gpus N` without a launcher: start N fresh ranks (one per GPU) BEFORE this process touches a GPU, pass rank 0's
+    line through, and refuse to print a line whose n_gpus is not the world size that ran."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, env=env)
+    line = None
+    for raw in proc.stdout.decode(errors="replace").splitlines():
+        if raw.startswith("{"):
+            line = raw
+    if proc.returncode != 0 or line is None:
+        sys.stderr.write(f"bench.py: the {args.gpus}-rank run failed (exit {proc.returncode}); no result line\n")
+        return proc.returncode or 1
+    got = json.loads(line)
+    if got.get("n_gpus") != args.gpus:
+        sys.stderr.write(f"bench.py: asked for {args.gpus} GPUs but the run reports n_gpus = {got.get('n_gpus')}: refusing to print it\n")
+        return 1
+    sys.stdout.write(line + "\n")
+    sys.stdout.flush()
+    return 0
+
+
+# ------------------------------------------------------------------------------------------------ CPU baseline
 def cpu_baseline(log_n: int):
     """The CPU oracle (reference-faithful C restatement, single thread like the reference) timed
     on this host: a reported baseline, never the thing measured above.  A second figure times an honestly
@@ -100,8 +140,16 @@ def cpu_baseline(log_n: int):
     }
 
 
+# ------------------------------------------------------------------------------------------------ one rank
 def main():
     args = parse()
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is None and args.gpus > 1:
+        raise SystemExit(launch_ranks(args))  # this process never initialises a GPU
+    world = int(world_env) if world_env is not None else 1
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: the line would be mislabelled")
+
     # stdout carries exactly ONE JSON line: libraries (RCCL prints a version banner on fd 1) write to stderr instead
     sys.stdout.flush()
     json_fd = os.dup(1)
@@ -109,11 +157,9 @@ def main():
 
     def emit(obj):
         os.write(json_fd, (json.dumps(obj) + "\n").encode())
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world != 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
     import numpy as np
     import torch
@@ -125,64 +171,69 @@ def main():
         import torch.distributed as dist_mod
 
         if world == 1 and "MASTER_ADDR" not in os.environ:
-            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
-
+            with socket.socket() as s:
+                s.bind(("127.0.0.1", 0))
+                port = s.getsockname()[1]
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
         dist = dist_mod
         if args.shared_device:
+            if args.backend == "nccl" and world > 1:
+                raise SystemExit("bench.py: --shared-device needs --backend gloo (RCCL refuses two ranks on one GPU)")
             local_rank = 0
         torch.cuda.set_device(local_rank)
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(args.backend)
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"bench.py: process group has {dist.get_world_size()} ranks, --gpus {args.gpus}")
 
     if dist is not None:
         result = bench_sharded(args, zk_amd, np, dist, rank, local_rank, world)
-    elif args.workload == "gkr":
-        emit(bench_gkr(args, zk_amd.Context(local_rank), zk_amd, np))
-        return
     else:
         ctx = zk_amd.Context(local_rank)
-        if args.fold_batch:
-            ctx.set_fold_batch(args.fold_batch, args.fold_variant)
-        if args.wide_batch >= 0:
-            ctx.set_wide_fold(args.wide_batch, args.wide_min_log_out, args.wide_lds_below)
-        if args.tail_max_log >= 0:
-            ctx.set_tail_fold(args.tail_max_log, args.tail_out_below)
-        result = bench_single(args, ctx, zk_amd, np)
+        apply_knobs(args, ctx)
+        if args.workload == "gkr":
+            emit(bench_gkr(args, ctx, zk_amd, np, args.gkr_depth, args.gkr_log_width, args.steps, args.warmup))
+            return
+        result = bench_single(args, ctx, zk_amd, np, args.workload, args.log_n, args.steps, args.warmup, absorb=not args.no_absorb)
+        if not args.no_extra:
+            result["extra"] = extra_workloads(args, ctx, zk_amd, np, torch)
 
     torch.cuda.synchronize()
-    barrier()
+    if dist is not None:
+        dist.barrier()
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
         return
 
+    n_ranks = dist.get_world_size() if dist is not None else 1
+    rccl = dist is not None and (result.get("transport") == "rccl" or (args.sharded_impl == "py" and dist.get_backend() == "nccl"))
     out = {
-        "metric": "sumcheck prove ms + field elems/s at 2^28-entry MLE, 1/8 GPUs; % HBM roofline",
+        "metric": METRIC,
         "value": result["elems_per_s"],
         "unit": "field elems/s",
-        "n_gpus": args.gpus,
+        "n_gpus": n_ranks,  # the world size that actually ran
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": result["ms_per_step"],
         "higher_is_better": True,
-        "scaling": "weak" if (world == 1 or args.weak) else "strong",
+        "scaling": "weak" if (n_ranks == 1 or args.weak) else "strong",
         "vs_baseline": None,
-        "dtype": "u32x8 (254-bit Montgomery, BN254 Fq)",
+        "dtype": DTYPE,
         "data": "synthetic (seeded splitmix64, full-range field elements)",
         "config": result["config"],
         "roofline": result["roofline"],
         "prove_ms": result["ms_per_step"],
+        "backend": dist.get_backend() if dist is not None else None,
+        "transport": result.get("transport"),
+        "rccl_ranks": n_ranks if rccl else 0,
     }
-    for k in ("absorb_ms", "inclusive_ms", "kernels", "int32_alu", "survey_8d_equivalent", "proof_check"):
+    for k in ("absorb_ms", "inclusive_ms", "kernels", "int32_alu", "survey_8d_equivalent", "proof_check", "extra"):
         if k in result:
             out[k] = result[k]
-    if not args.no_cpu_baseline and world == 1 and args.workload == "mle":
+    if not args.no_cpu_baseline and n_ranks == 1 and args.workload == "mle":
         out["cpu_baseline"] = cpu_baseline(args.cpu_log_n)
     else:
         out["cpu_baseline"] = None
@@ -191,62 +242,22 @@ def main():
         dist.destroy_process_group()
 
 
-def bench_single(args, ctx, zk_amd, np):
-    import torch
+def apply_knobs(args, ctx):
+    if args.fold_batch:
+        ctx.set_fold_batch(args.fold_batch, args.fold_variant)
+    if args.wide_batch >= 0:
+        ctx.set_wide_fold(args.wide_batch, args.wide_min_log_out, args.wide_lds_below)
+    if args.tail_max_log >= 0:
+        ctx.set_tail_fold(args.tail_max_log, args.tail_out_below)
+    if args.deg2_rounds:
+        ctx.set_deg2_rounds_per_pass(args.deg2_rounds)
+    if args.deg2_lazy_from is not None:
+        ctx.set_deg2_lazy_sums(args.deg2_lazy_from)
 
-    n = 1 << args.log_n
-    if args.workload == "mle":
-        poly = zk_amd.MultiLinearPolynomial.generate(SEED, n, ctx=ctx)
-        base = zk_amd.Transcript()
-        absorb_ms = None
-        if not args.no_absorb:
-            # transcript.append(&init_polynomial.to_bytes()) (prover.rs:162): once, outside the timed region
-            t0 = time.perf_counter()
-            absorb_table(zk_amd, ctx, poly, base)
-            absorb_ms = (time.perf_counter() - t0) * 1e3
-        else:
-            base.append(b"bench: table absorb skipped (--no-absorb)")
 
-        def step():
-            return zk_amd.SumcheckProver.generate_round_polys(poly, base.clone())
-
-        kernel, workload = "multifold", f"single-MLE sumcheck, 2^{args.log_n} entries, 1 GPU"
-    else:
-        tabs = [zk_amd.MultiLinearPolynomial.generate(SEED + k, n, ctx=ctx) for k in range(4)]
-        f = zk_amd.SumPolynomial([zk_amd.ProductPolynomial(tabs[:2]), zk_amd.ProductPolynomial(tabs[2:])])
-        base = zk_amd.Transcript()
-        base.append(b"bench: degree-2 sum of two products")
-        claim = np.zeros(4, dtype=np.uint64)
-        absorb_ms = None
-
-        def step():
-            return zk_amd.SumcheckProver.generate_proof_for_partial_verify(claim, f, base.clone())
-
-        if args.deg2_rounds:
-            ctx.set_deg2_rounds_per_pass(args.deg2_rounds)
-        if args.deg2_lazy_from is not None:
-            ctx.set_deg2_lazy_sums(args.deg2_lazy_from)
-        kernel = "fold4_eval3" if args.deg2_rounds == 1 else "fold2x4_sum9"
-        workload = f"degree-2 sumcheck Sum[Prod[f,g],Prod[h,k]], 4 x 2^{args.log_n} entries, 1 GPU"
-
-    for _ in range(args.warmup):
-        step()
-    ctx.prof_enable(True)
-    ctx.prof_reset()
-    ctx.synchronize()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    last = None
-    for _ in range(args.steps):
-        last = step()
-    ctx.synchronize()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    ctx.prof_enable(False)
-    ms_per_step = dt * 1e3 / args.steps
-
+def read_kernels(ctx, names=KERNEL_NAMES):
     kernels = {}
-    for name in ("block_sums", "multifold_wide", "multifold", "multifold_tail", "eval3", "fold4_eval3", "sum9", "fold2x4_sum9"):
+    for name in names:
         p = ctx.prof_read(name)
         if p["launches"]:
             kernels[name] = {
@@ -254,38 +265,121 @@ def bench_single(args, ctx, zk_amd, np):
                 "alg_bytes_per_launch": p["alg_bytes"] / p["launches"],
                 "achieved_GBs": p["alg_bytes"] / (p["ms"] * 1e-3) / 1e9 if p["ms"] > 0 else None,
             }
-    if kernel == "multifold":  # the fold pass the time goes to: the wide pass over the full table when there is one
-        kernel = next(k for k in ("multifold_wide", "multifold", "multifold_tail", "block_sums") if k in kernels)
-    dom = kernels[kernel]
-    roofline = {
-        "bound": "hbm", "kernel": kernel, "achieved": dom["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": dom["achieved_GBs"] / HBM_PEAK_GBS, "traffic": pmc_traffic(kernel, args.log_n),
-        "note": "achieved = algorithmic bytes of all launches of the kernel in the timed steps / their summed "
-                "HIP-event durations (multifold / multifold_wide: 32 B per input entry read + 32 B per output entry written; "
-                "fold4_eval3: 48 B per input entry per table; fold2x4_sum9: 32 B per input + 32 B per output entry per table)",
-    }
-    # int32-ALU side: Montgomery multiplies per second from the in-register probe
+    return kernels
+
+
+_mad_peak = {}
+
+
+def mad_peak(ctx) -> float:
+    """lane multiply-adds per second of the v_mad_u64_u32 issue probe (measured live, once per context)."""
+    key = id(ctx)
+    if key not in _mad_peak:
+        blocks, iters = 2048, 200  # 8 waves per SIMD
+        ms = min(ctx.bench_mad(blocks, iters) for _ in range(2))
+        _mad_peak[key] = blocks * 256 * iters * 256 / (ms * 1e-3)
+    return _mad_peak[key]
+
+
+def int32_alu(ctx, kernels):
+    """The int32-ALU roofline beside the HBM one: limb multiply-adds per second of the two product-heavy kernels against the
+    measured v_mad_u64_u32 issue ceiling of the chip, and which of the two rooflines binds each."""
+    peak = mad_peak(ctx)
     blocks, iters = 2048, 2000
-    ms = ctx.bench_modmul(blocks, iters)
-    modmul_per_s = blocks * 256 * iters / (ms * 1e-3)
-    alu = {"modmul_per_s": modmul_per_s, "note": "peak = dependent fq_mul chain, 2048x256 lanes (k_modmul_probe)"}
-    if "multifold_wide" in kernels:  # the wide fold pass: one 9x9-limb inner product (81 v_mad_u64_u32) per input entry
+    modmul_per_s = blocks * 256 * iters / (ctx.bench_modmul(blocks, iters) * 1e-3)
+    hbm = {k: v["achieved_GBs"] / HBM_PEAK_GBS for k, v in kernels.items() if v["achieved_GBs"]}
+    alu = {"peak_lane_mads_per_s": peak,
+           "peak_note": "k_mad_probe: 2048 x 256 lanes, four independent v_mad_u64_u32 chains per lane, measured in this run",
+           "modmul_per_s_dependent_chain": modmul_per_s}
+    if "multifold_wide" in kernels:  # one 9x9-limb inner product (81 v_mad_u64_u32) per input entry
         k = kernels["multifold_wide"]
         entries = k["alg_bytes_per_launch"] / 32.0 * 256 / 257
         alu["fold_pass_limb_mads_per_s"] = 81 * entries / (k["avg_ms"] * 1e-3)
-        alu["fold_pass_products_equiv_frac"] = (entries / (k["avg_ms"] * 1e-3)) / modmul_per_s  # products of 81 of fq_mul's ~270 ops: memory-bound by design
-    if "sum9" in kernels:            # nine-sum sweeps: 18 field products per quarter-index (16 entries of 32 B)
+        alu["fold_pass_frac"] = alu["fold_pass_limb_mads_per_s"] / peak
+        alu["fold_pass_hbm_frac"] = hbm.get("multifold_wide")
+        alu["fold_pass_binds"] = "hbm" if hbm.get("multifold_wide", 0) >= alu["fold_pass_frac"] else "int32"
+    if "sum9" in kernels:            # nine-sum sweeps: 18 field products per quarter-index (16 entries of 32 B), 82 limb products each
         k = kernels["sum9"]
         prod = 18 * k["alg_bytes_per_launch"] * k["launches"] / 512.0
         alu["sum9_products_per_s"] = prod / (k["total_ms"] * 1e-3)
-        alu["sum9_frac_of_modmul_peak"] = alu["sum9_products_per_s"] / modmul_per_s
+        alu["sum9_limb_mads_per_s"] = 82 * alu["sum9_products_per_s"]
+        alu["sum9_frac"] = alu["sum9_limb_mads_per_s"] / peak
+        alu["sum9_hbm_frac"] = hbm.get("sum9")
+        alu["sum9_binds"] = "hbm" if hbm.get("sum9", 0) >= alu["sum9_frac"] else "int32"
+    return alu
+
+
+def bench_single(args, ctx, zk_amd, np, workload, log_n, steps, warmup, absorb=False, want_alu=True):
+    import torch
+
+    n = 1 << log_n
+    absorb_ms = None
+    if workload == "mle":
+        poly = zk_amd.MultiLinearPolynomial.generate(SEED, n, ctx=ctx)
+        base = zk_amd.Transcript()
+        if absorb:
+            # transcript.append(&init_polynomial.to_bytes()) (prover.rs:162): once, outside the timed region
+            t0 = time.perf_counter()
+            absorb_table(zk_amd, ctx, poly, base)
+            absorb_ms = (time.perf_counter() - t0) * 1e3
+        else:
+            base.append(b"bench: table absorb skipped")
+
+        def step():
+            return zk_amd.SumcheckProver.generate_round_polys(poly, base.clone())
+
+        kernel, what = "multifold", f"single-MLE sumcheck, 2^{log_n} entries, 1 GPU"
+    else:
+        tabs = [zk_amd.MultiLinearPolynomial.generate(SEED + k, n, ctx=ctx) for k in range(4)]
+        f = zk_amd.SumPolynomial([zk_amd.ProductPolynomial(tabs[:2]), zk_amd.ProductPolynomial(tabs[2:])])
+        base = zk_amd.Transcript()
+        base.append(b"bench: degree-2 sum of two products")
+        claim = np.zeros(4, dtype=np.uint64)
+
+        def step():
+            return zk_amd.SumcheckProver.generate_proof_for_partial_verify(claim, f, base.clone())
+
+        kernel = "fold4_eval3" if args.deg2_rounds == 1 else "fold2x4_sum9"
+        what = f"degree-2 sumcheck Sum[Prod[f,g],Prod[h,k]], 4 x 2^{log_n} entries, 1 GPU"
+
+    for _ in range(warmup):
+        step()
+    ctx.prof_enable(True)
+    ctx.prof_reset()
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ctx.prof_enable(False)
+    ms_per_step = dt * 1e3 / steps
+
+    kernels = read_kernels(ctx)
+    if kernel == "multifold":  # the fold pass the time goes to: the wide pass over the full table when there is one
+        kernel = next(k for k in ("multifold_wide", "multifold", "multifold_tail", "block_sums") if k in kernels)
+    if kernel not in kernels:
+        kernel = max(kernels, key=lambda k: kernels[k]["total_ms"])
+    dom = kernels[kernel]
+    roofline = {
+        "bound": "hbm", "kernel": kernel, "achieved": dom["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": dom["achieved_GBs"] / HBM_PEAK_GBS,
+        # PMC counters cannot be read from inside the process: null here, and the committed rocprofv3 passes of this same command named beside it
+        "traffic": None, "traffic_source": pmc_traffic(kernel, log_n) if workload == "mle" else None,
+        "note": "achieved = algorithmic bytes of all launches of the kernel in the timed steps / their summed "
+                "HIP-event durations on the context's stream (multifold / multifold_wide: 32 B per input entry read + 32 B per output entry written; "
+                "fold4_eval3: 48 B per input entry per table; fold2x4_sum9: 32 B per input + 32 B per output entry per table; sum9 / block_sums: 32 B per entry)",
+    }
     res = {
         "elems_per_s": n / (ms_per_step * 1e-3), "ms_per_step": ms_per_step, "roofline": roofline, "kernels": kernels,
-        "int32_alu": alu,
-        "config": {"workload": workload, "log_n": args.log_n, "field": "BN254 Fq",
+        "config": {"workload": what, "log_n": log_n, "field": "BN254 Fq",
                    "parallelism": "1 GPU", "transcript": "Keccak-256 on host, one challenge per round"},
     }
-    if args.workload == "mle":
+    if want_alu:
+        res["int32_alu"] = int32_alu(ctx, kernels)
+    if workload == "mle":
         # SURVEY.md 8(d) prices a whole prove at 128*N bytes (one fused fold + sum per round).  Batching rounds REMOVES
         # traffic (this build moves ~64*N), so that figure over the prove time exceeds what HBM delivers: it is reported
         # as an equivalent rate only; roofline.achieved above counts the bytes the dominant kernel really has to move.
@@ -297,9 +391,42 @@ def bench_single(args, ctx, zk_amd, np):
     return res
 
 
+def extra_workloads(args, ctx, zk_amd, np, torch):
+    """The other workloads north_star asks the benchmark to report, in the same driver-run line: a size sweep of the
+    single-MLE prove, the degree-2 prove at 4 x 2^26 (config 4's shape on one GPU) and the GKR config-5 prove.  Three timed
+    steps each; every entry carries its prove time, rate and the HBM fraction of its dominant kernel."""
+    import gc
+
+    out = {"note": "steps 3, warmup 1 each; single GPU; same library calls and timing brackets as the headline workload"}
+    gc.collect()
+    sweep = []
+    sizes = [20, 24, 28]
+    free, _total = torch.cuda.mem_get_info()
+    if free > (45 << 30):
+        sizes.append(30)  # 32 GiB table
+    for log_n in sizes:
+        r = bench_single(args, ctx, zk_amd, np, "mle", log_n, 3, 1, absorb=False, want_alu=False)
+        sweep.append({"log_n": log_n, "prove_ms": r["ms_per_step"], "elems_per_s": r["elems_per_s"], "dominant_kernel": r["roofline"]["kernel"],
+                      "hbm_frac": r["roofline"]["frac"],
+                      "kernels": {k: {"avg_ms": v["avg_ms"], "launches_per_prove": v["launches"] / 3, "GBs": v["achieved_GBs"]} for k, v in r["kernels"].items()}})
+        gc.collect()
+    out["mle_sweep"] = sweep
+    r = bench_single(args, ctx, zk_amd, np, "sum2x2", 26, 3, 1)
+    out["sum2x2_log26"] = {"workload": r["config"]["workload"], "prove_ms": r["ms_per_step"], "entries_per_s": 4 * (1 << 26) / (r["ms_per_step"] * 1e-3),
+                           "roofline": {k: r["roofline"][k] for k in ("kernel", "achieved", "peak", "unit", "frac")},
+                           "kernels": r["kernels"], "int32_alu": r.get("int32_alu")}
+    gc.collect()
+    g = bench_gkr(args, ctx, zk_amd, np, 16, 20, 3, 1)
+    out["gkr_config5"] = {k: g[k] for k in ("config", "prove_ms", "value", "unit", "layers_ms_total", "ms_per_round", "circuit_evaluate_ms",
+                                            "output_absorb_ms", "note")}
+    return out
+
+
 def bench_sharded(args, zk_amd, np, dist, rank, local_rank, world):
-    """One rank per GPU; the 2^log_n-entry table is sharded on the variables bound last
-    (zk_amd/sharded.py).  Strong scaling by default (the metric's 2^28 entries in total)."""
+    """One rank per GPU; the 2^log_n-entry table is sharded on the variables bound last.  Strong scaling by default (the
+    metric's 2^28 entries in total).  --sharded-impl lib (default): the loop and the exchange run inside libzkmi.so
+    (zk_sumcheck_prove_*_sharded: RCCL ncclAllGather on the context stream with the nccl backend, host all-gather through
+    torch.distributed otherwise); py: zk_amd/sharded.py over torch.distributed."""
     import torch
 
     from zk_amd import sharded
@@ -311,34 +438,38 @@ def bench_sharded(args, zk_amd, np, dist, rank, local_rank, world):
         raise SystemExit("world size must be a power of two")
     log_total = args.log_n + (g if args.weak else 0)
     n_local = 1 << (log_total - g)
-    ctx = sharded.torch_stream_context(local_rank)
-    if args.fold_batch:
-        ctx.set_fold_batch(args.fold_batch, args.fold_variant)
-    if args.wide_batch >= 0:
-        ctx.set_wide_fold(args.wide_batch, args.wide_min_log_out, args.wide_lds_below)
-    if args.tail_max_log >= 0:
-        ctx.set_tail_fold(args.tail_max_log, args.tail_out_below)
+    use_lib = args.sharded_impl == "lib"
+    ctx = zk_amd.Context(local_rank) if use_lib else sharded.torch_stream_context(local_rank)
+    apply_knobs(args, ctx)
+    transport = sharded.comm_init(ctx, dist) if use_lib else ("rccl" if dist.get_backend() == "nccl" else "host")
     gather_log = args.gather_log if args.gather_log >= 0 else None
-    fold_batch = None  # the library's schedule (zk_shard_next_batch): the same passes as the single-GPU prover
     base = zk_amd.Transcript()
     base.append(b"bench: table absorb skipped (sharded run; SURVEY.md H1)")
+    if use_lib:
+        via = "in-library loop, " + ("ncclAllGather on the context stream" if transport == "rccl" else f"host all-gather through {dist.get_backend()}")
+    else:
+        via = f"zk_amd/sharded.py over torch.distributed ({dist.get_backend()})"
     if args.workload == "mle":
         poly = zk_amd.MultiLinearPolynomial.generate(SEED, n_local, first=rank, step=world, ctx=ctx)
 
         def step():
+            if use_lib:
+                return sharded.prove_mle_sharded(poly, base.clone(), False, gather_log)
             sh = sharded.DeviceShard(poly)
             try:
-                return sharded.generate_round_polys_sharded(sh, base.clone(), world, dist, None, fold_batch, gather_log)
+                return sharded.generate_round_polys_sharded(sh, base.clone(), world, dist, None, None, gather_log)
             finally:
                 sh.close()
 
         dom_kernel, names = "multifold", ("block_sums", "multifold_wide", "multifold", "multifold_tail")
         what = f"single-MLE sumcheck, 2^{log_total} entries"
-        exchange = f"all-gather of 2^m block sums per pass ({dist.get_backend()}), library pass schedule; tables of <= 2^{args.gather_log} entries per rank all-gathered and finished on every rank"
+        exchange = f"all-gather of 2^m block sums per pass ({via}), library pass schedule; tables of <= 2^{args.gather_log} entries per rank all-gathered and finished on every rank"
     else:
         tabs = [zk_amd.MultiLinearPolynomial.generate(SEED + k, n_local, first=rank, step=world, ctx=ctx) for k in range(4)]
 
         def step():
+            if use_lib:
+                return sharded.prove_sum2x2_sharded(tabs, base.clone(), None, gather_log)
             sh = sharded.DeviceShard4(tabs)
             try:
                 return sharded.generate_round_polys_sum2x2_sharded(sh, base.clone(), world, dist, None, gather_log)
@@ -347,20 +478,22 @@ def bench_sharded(args, zk_amd, np, dist, rank, local_rank, world):
 
         dom_kernel, names = ("fold4_eval3", ("eval3", "fold4_eval3")) if gather_log is None else ("fold2x4_sum9", ("sum9", "fold2x4_sum9"))
         what = f"degree-2 sumcheck Sum[Prod[f,g],Prod[h,k]], 4 x 2^{log_total} entries"
-        exchange = (f"all-gather of 3 evaluation shares per round ({dist.get_backend()})" if gather_log is None else
-                    f"all-gather of nine sums per two rounds ({dist.get_backend()}); tables of <= 2^{gather_log} entries per rank all-gathered and finished on every rank")
+        exchange = (f"all-gather of 3 evaluation shares per round ({via})" if gather_log is None else
+                    f"all-gather of nine sums per two rounds ({via}); tables of <= 2^{gather_log} entries per rank all-gathered and finished on every rank")
 
     for _ in range(args.warmup):
         step()
     ctx.prof_enable(True)
     ctx.prof_collect()
     ctx.prof_reset()
+    ctx.synchronize()
     torch.cuda.synchronize()
     dist.barrier()
     t0 = time.perf_counter()
     last = None
     for _ in range(args.steps):
         last = step()
+    ctx.synchronize()
     torch.cuda.synchronize()
     dist.barrier()
     dt = time.perf_counter() - t0
@@ -380,15 +513,7 @@ def bench_sharded(args, zk_amd, np, dist, rank, local_rank, world):
     same = bool(torch.equal(lo, hi))
     ms_per_step = float(tmax.item()) * 1e3 / args.steps
 
-    kernels = {}
-    for name in names:
-        p = ctx.prof_read(name)
-        if p["launches"]:
-            kernels[name] = {
-                "launches": p["launches"], "total_ms": p["ms"], "avg_ms": p["ms"] / p["launches"],
-                "alg_bytes_per_launch": p["alg_bytes"] / p["launches"],
-                "achieved_GBs": p["alg_bytes"] / (p["ms"] * 1e-3) / 1e9 if p["ms"] > 0 else None,
-            }
+    kernels = read_kernels(ctx, names)
     if dom_kernel == "multifold":
         dom_kernel = next(k for k in ("multifold_wide", "multifold", "multifold_tail", "block_sums") if k in kernels)
     dom = kernels[dom_kernel]
@@ -399,9 +524,11 @@ def bench_sharded(args, zk_amd, np, dist, rank, local_rank, world):
                 "their summed HIP-event durations (multifold: 32 B per input entry read + 32 B per output entry written; "
                 "fold4_eval3: 48 B per input entry per table)",
     }
+    if use_lib:
+        sharded.comm_destroy(ctx)
     return {
         "elems_per_s": (1 << log_total) / (ms_per_step * 1e-3), "ms_per_step": ms_per_step, "roofline": roofline,
-        "kernels": kernels, "proof_check": {"all_ranks_identical": same},
+        "kernels": kernels, "proof_check": {"all_ranks_identical": same}, "transport": transport,
         "config": {"workload": f"{what} sharded over {world} GPUs (2^{log_total - g} per GPU, low-bit sharding)",
                    "log_n": log_total, "field": "BN254 Fq", "parallelism": f"table-sharded x{world}",
                    "exchange": exchange,
@@ -409,15 +536,14 @@ def bench_sharded(args, zk_amd, np, dist, rank, local_rank, world):
     }
 
 
-def bench_gkr(args, ctx, zk_amd, np):
+def bench_gkr(args, ctx, zk_amd, np, depth, k, steps, warmup):
     """Full GKR prove (gkr/src/prover.rs:24-154) of a layered circuit: circuit evaluation, predicate
     folding from the gate lists and every layer's degree-2 sumcheck on the device."""
     import torch
 
-    depth, k = args.gkr_depth, args.gkr_log_width
-    t0 = time.perf_counter()
     from zk_amd.synthetic import gkr_layers
 
+    t0 = time.perf_counter()
     circuit = zk_amd.Circuit.from_arrays(gkr_layers(depth, k), ctx=ctx)
     build_ms = (time.perf_counter() - t0) * 1e3
     inputs = zk_amd.MultiLinearPolynomial.generate(SEED, 1 << k, ctx=ctx)
@@ -425,23 +551,23 @@ def bench_gkr(args, ctx, zk_amd, np):
     def step(timing=False):
         return zk_amd.GKRProver.generate_proof(circuit, zk_amd.Transcript(), inputs, timing=timing)
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     ctx.synchronize()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         proof = step()
     ctx.synchronize()
     torch.cuda.synchronize()
-    ms = (time.perf_counter() - t0) * 1e3 / args.steps
+    ms = (time.perf_counter() - t0) * 1e3 / steps
     timed = step(timing=True)
     gates = depth << k
     rounds = sum(p.round_polys.shape[0] for p in proof.sumcheck_proofs)
     return {
         "metric": "GKR prove ms + gates/s, layered circuit, wiring predicates built on device", "value": gates / (ms * 1e-3),
-        "unit": "gates/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "u32x8 (254-bit Montgomery, BN254 Fq)",
+        "unit": "gates/s", "n_gpus": 1, "steps": steps, "warmup": warmup, "ms_per_step": ms, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": DTYPE,
         "data": "synthetic (SURVEY.md 8d config 5 wiring, seeded inputs)",
         "config": {"workload": f"GKR prove, depth {depth}, 2^{k} gates per layer", "depth": depth, "log_width": k,
                    "sumcheck_rounds": rounds, "field": "BN254 Fq"},
@@ -455,9 +581,8 @@ def bench_gkr(args, ctx, zk_amd, np):
 
 
 def pmc_traffic(kernel: str, log_n: int):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 counter passes of this same
-    command (profiles/*hbm_traffic.json; counters cannot be read from inside the process).  None
-    when no committed pass matches the workload."""
+    """The committed rocprofv3 counter passes of this same command (profiles/*hbm_traffic.json): HBM bytes per launch of
+    `kernel` and the file they come from.  Not this run's counters -- PMC cannot be read from inside the process."""
     import glob
 
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*hbm_traffic.json")), reverse=True):
@@ -467,7 +592,7 @@ def pmc_traffic(kernel: str, log_n: int):
         except (OSError, ValueError):
             continue
         if d.get("log_n") == log_n and kernel in d.get("kernels", {}):
-            return d["kernels"][kernel]["bytes_per_launch"]
+            return {"file": os.path.relpath(path, ROOT) + " (committed)", "bytes_per_launch": d["kernels"][kernel]["bytes_per_launch"]}
     return None
 
 

@@ -355,6 +355,9 @@ int zk_prof_read(zk_ctx *ctx, int kernel, uint64_t *launches, double *ms, uint64
 /* Montgomery-multiply throughput probe: `iters` dependent multiplies per lane on `blocks` x 256
  * lanes; returns elapsed ms.  Used for the int32-ALU roofline figure. */
 int zk_bench_modmul(zk_ctx *ctx, int blocks, int iters, double *ms_out);
+/* v_mad_u64_u32 issue-rate probe: blocks x 256 lanes, iters x 256 independent multiply-adds per lane; elapsed ms.
+ * lane-MADs per second = blocks * 256 * iters * 256 / time: the int32-ALU ceiling of the limb-product loops. */
+int zk_bench_mad(zk_ctx *ctx, int blocks, int iters, double *ms_out);
 
 #if defined(__GNUC__)
 #pragma GCC visibility pop

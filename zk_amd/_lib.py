@@ -117,6 +117,7 @@ SYMBOLS = [
     ("zk_prof_collect", C.c_int, [_VP]),
     ("zk_prof_read", C.c_int, [_VP, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     ("zk_bench_modmul", C.c_int, [_VP, C.c_int, C.c_int, C.POINTER(C.c_double)]),
+    ("zk_bench_mad", C.c_int, [_VP, C.c_int, C.c_int, C.POINTER(C.c_double)]),
 ]
 
 _lib = None

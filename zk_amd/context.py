@@ -89,6 +89,12 @@ class Context:
         check(lib().zk_bench_modmul(self.h, blocks, iters, C.byref(ms)), self.h)
         return ms.value
 
+    def bench_mad(self, blocks: int, iters: int) -> float:
+        """ms for blocks*256 lanes x iters*256 independent v_mad_u64_u32 (the int32-ALU issue ceiling)."""
+        ms = C.c_double()
+        check(lib().zk_bench_mad(self.h, blocks, iters, C.byref(ms)), self.h)
+        return ms.value
+
     def close(self):
         if getattr(self, "h", None):
             lib().zk_ctx_destroy(self.h)

@@ -85,6 +85,8 @@ void launch_from_le32(const void* in, void* out, size_t n, hipStream_t st);
 void launch_to_le32(const void* in, void* out, size_t n, hipStream_t st);
 void launch_generate(void* out, uint64_t seed, uint64_t first, uint64_t step, size_t n, hipStream_t st);
 void launch_modmul_probe(void* io, int blocks, int iters, hipStream_t st);
+// out: blocks * 256 u32; every lane issues iters * 256 v_mad_u64_u32
+void launch_mad_probe(void* out, int blocks, int iters, hipStream_t st);
 
 // ---- static scratch of the entry point that allocates nothing (zk_fold_block_sums_noalloc) ----
 // One file-scope __device__ array per GPU (kernels.hip): [0, kStaticPartialsBytes) per-workgroup partial sums of a fold

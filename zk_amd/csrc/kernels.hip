@@ -1023,6 +1023,23 @@ __global__ void __launch_bounds__(kThreads) k_modmul_probe(fq* __restrict__ io, 
     fq_store(io + i, a);
 }
 
+// Issue-rate probe for the int32-ALU roofline: four independent v_mad_u64_u32 chains per lane, 256 multiply-adds per
+// loop trip, nothing else in the loop -- the ceiling every limb-product loop of this file runs against.
+__global__ void __launch_bounds__(kThreads) k_mad_probe(u32* __restrict__ out, int iters) {
+    const u32 t = threadIdx.x;
+    u64 a0 = t, a1 = t + 1, a2 = t + 2, a3 = t + 3;
+    const u32 x = t | 1, y = (t << 7) | 5;
+    for (int k = 0; k < iters; ++k) {
+#pragma unroll
+        for (int j = 0; j < 64; ++j)
+            asm volatile("v_mad_u64_u32 %0, vcc, %4, %5, %0\n\tv_mad_u64_u32 %1, vcc, %4, %5, %1\n\tv_mad_u64_u32 %2, vcc, %4, %5, %2\n\tv_mad_u64_u32 %3, vcc, %4, %5, %3"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3)
+                         : "v"(x), "v"(y)
+                         : "vcc");
+    }
+    out[(size_t)blockIdx.x * kThreads + threadIdx.x] = (u32)(a0 + a1 + a2 + a3);
+}
+
 // ---- launchers ---------------------------------------------------------------------------
 static inline int grid_for(size_t work) {
     size_t b = (work + kThreads - 1) / kThreads;
@@ -1304,6 +1321,9 @@ void launch_generate(void* out, uint64_t seed, uint64_t first, uint64_t step, si
 }
 void launch_modmul_probe(void* io, int blocks, int iters, hipStream_t st) {
     hipLaunchKernelGGL(k_modmul_probe, dim3(blocks), dim3(kThreads), 0, st, (fq*)io, iters);
+}
+void launch_mad_probe(void* out, int blocks, int iters, hipStream_t st) {
+    hipLaunchKernelGGL(k_mad_probe, dim3(blocks), dim3(kThreads), 0, st, (u32*)out, iters);
 }
 
 // ---- static scratch (zk_fold_block_sums_noalloc: the entry point that allocates nothing) ----------------------

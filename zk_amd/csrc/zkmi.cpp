@@ -1105,6 +1105,28 @@ int zk_prof_read(zk_ctx* c, int kernel, uint64_t* launches, double* ms, uint64_t
     if (bytes) *bytes = c->prof_bytes[kernel];
     return ZK_OK;
 }
+int zk_bench_mad(zk_ctx* c, int blocks, int iters, double* ms_out) {
+    if (!c || blocks <= 0 || iters <= 0 || !ms_out) return ZK_E_ARG;
+    int rc = set_device(c);
+    if (rc) return rc;
+    void* buf = nullptr;
+    HIPCHK(c, hipMalloc(&buf, (size_t)blocks * 256 * sizeof(uint32_t)));
+    hipEvent_t a, b;
+    HIPCHK(c, hipEventCreate(&a));
+    HIPCHK(c, hipEventCreate(&b));
+    zkk::launch_mad_probe(buf, blocks, 2, c->stream); // warm-up
+    HIPCHK(c, hipEventRecord(a, c->stream));
+    zkk::launch_mad_probe(buf, blocks, iters, c->stream);
+    HIPCHK(c, hipEventRecord(b, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    float ms = 0;
+    HIPCHK(c, hipEventElapsedTime(&ms, a, b));
+    *ms_out = ms;
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    HIPCHK(c, hipFree(buf));
+    return ZK_OK;
+}
 int zk_bench_modmul(zk_ctx* c, int blocks, int iters, double* ms_out) {
     if (!c || blocks <= 0 || iters <= 0 || !ms_out) return ZK_E_ARG;
     int rc = set_device(c);
