@@ -109,6 +109,12 @@ int zk_mle_download_mont(const zk_mle *m, uint64_t *out_limbs);             /* g
 int zk_mle_to_le32(const zk_mle *m, uint8_t *out_bytes);                    /* to_bytes :225-234 (32*len bytes) */
 /* partially_evaluate((var, r)) :163-192 with the pairing of get_y1_y2_indexes :45-80 -> new table of len/2 */
 int zk_mle_partially_evaluate(const zk_mle *m, size_t var, const uint64_t r_mont[4], zk_mle **out);
+/* compute_quotient_remainder(&divisor, variable_index) :280-301 (the division step of the multilinear-KZG opening,
+ * kzg/src/multilinear/prover.rs:77): quotient[k] = y2 - y1 over the pairs of get_y1_y2_indexes(var) in their order (a
+ * Vec<T> of len/2 elements, returned as a table), remainder = partially_evaluate((var, divisor)).  One pass, two outputs. */
+int zk_mle_quotient_remainder(const zk_mle *m, size_t var, const uint64_t divisor_mont[4], zk_mle **quotient_out,
+                              zk_mle **remainder_out);
+int zk_mle_minus(const zk_mle *m, const uint64_t v_mont[4], zk_mle **out);  /* minus :260-272: F(x) - V */
 /* evaluate(&[Option<T>]) :194-223; has[i] != 0 means Some(vals[i]).  npts must equal log2(len). */
 int zk_mle_evaluate(const zk_mle *m, const uint8_t *has, const uint64_t *vals_mont, size_t npts, zk_mle **out);
 int zk_mle_evaluation_sum(const zk_mle *m, uint64_t out_mont[4]);           /* evaluation_sum :236-238 */

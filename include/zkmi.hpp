@@ -108,6 +108,14 @@ class MultiLinearPolynomial {
     std::vector<uint8_t> to_bytes() const { std::vector<uint8_t> b(32 * len()); ctx_->check(zk_mle_to_le32(h_, b.data())); return b; } // :225-234
     Fq evaluation_sum() const { Fq s; ctx_->check(zk_mle_evaluation_sum(h_, s.l)); return s; } // :236-238
     MultiLinearPolynomial scalar_mul(const Fq& s) const { zk_mle* o = nullptr; ctx_->check(zk_mle_scalar_mul(h_, s.l, &o)); return adopt(o, ctx_); } // :151-153
+    MultiLinearPolynomial minus(const Fq& other) const { zk_mle* o = nullptr; ctx_->check(zk_mle_minus(h_, other.l, &o)); return adopt(o, ctx_); } // :260-272
+    // compute_quotient_remainder(&divisor, variable_index) :280-301 -> (quotient: Vec<T>, remainder)
+    std::pair<std::vector<Fq>, MultiLinearPolynomial> compute_quotient_remainder(const Fq& divisor, size_t variable_index) const {
+        zk_mle *q = nullptr, *r = nullptr;
+        ctx_->check(zk_mle_quotient_remainder(h_, variable_index, divisor.l, &q, &r));
+        MultiLinearPolynomial quotient = adopt(q, ctx_);
+        return {quotient.get_evaluation_points(), adopt(r, ctx_)};
+    }
     MultiLinearPolynomial operator+(const MultiLinearPolynomial& b) const { zk_mle* o = nullptr; ctx_->check(zk_mle_add(h_, b.h_, &o)); return adopt(o, ctx_); } // :241-258
     static MultiLinearPolynomial w_add(const MultiLinearPolynomial& w_b, const MultiLinearPolynomial& w_c) { // :303-308
         zk_mle* o = nullptr; w_b.ctx_->check(zk_mle_w_add(w_b.h_, w_c.h_, &o)); return adopt(o, w_b.ctx_);

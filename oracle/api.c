@@ -91,6 +91,19 @@ API int orc_mle_scalar_mul(const uint64_t *table, size_t len, const uint64_t s[4
     mle_t m = {(fq_t *)table, len}, o; fq_t ss; memcpy(ss.l, s, 32);
     int rc = mle_scalar_mul(&o, &m, &ss); if (!rc) { memcpy(out, o.ev, o.len * 32); mle_free(&o); } return rc;
 }
+API int orc_mle_minus(const uint64_t *table, size_t len, const uint64_t v[4], uint64_t *out) {
+    mle_t m = {(fq_t *)table, len}, o; fq_t vv; memcpy(vv.l, v, 32);
+    int rc = mle_minus(&o, &m, &vv); if (!rc) { memcpy(out, o.ev, o.len * 32); mle_free(&o); } return rc;
+}
+/* quotient_out, remainder_out: 4 * len/2 limbs each */
+API int orc_mle_quotient_remainder(const uint64_t *table, size_t len, const uint64_t divisor[4], size_t var, uint64_t *quotient_out,
+                                   uint64_t *remainder_out) {
+    mle_t m, r; int rc = mle_new(&m, (const fq_t *)table, len); if (rc) return rc;
+    fq_t d; memcpy(d.l, divisor, 32);
+    rc = mle_compute_quotient_remainder((fq_t *)quotient_out, &r, &m, &d, var);
+    if (!rc) { memcpy(remainder_out, r.ev, r.len * 32); mle_free(&r); }
+    mle_free(&m); return rc;
+}
 API int orc_mle_add(const uint64_t *a, size_t la, const uint64_t *b, size_t lb, uint64_t *out) {
     mle_t x = {(fq_t *)a, la}, y = {(fq_t *)b, lb}, o;
     int rc = mle_add(&o, &x, &y); if (!rc) { memcpy(out, o.ev, o.len * 32); mle_free(&o); } return rc;

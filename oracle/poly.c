@@ -72,6 +72,29 @@ int mle_partially_evaluate(mle_t *out, const mle_t *m, size_t var, const fq_t *r
     return rc;
 }
 
+/* minus (evaluation_form.rs:260-272): F(x) - V, entry by entry */
+int mle_minus(mle_t *out, const mle_t *m, const fq_t *other) {
+    fq_t *nv = (fq_t *)malloc(m->len * sizeof(fq_t));
+    if (!nv) return ORC_E_ALLOC;
+    for (size_t i = 0; i < m->len; ++i) fq_sub(&nv[i], &m->ev[i], other); /* *val - *other, :267 */
+    int rc = mle_new(out, nv, m->len);
+    free(nv);
+    return rc;
+}
+
+/* compute_quotient_remainder (evaluation_form.rs:280-301): remainder = partially_evaluate((variable_index, divisor)) (:285),
+ * quotient[k] = y2 - y1 over the pairs of get_y1_y2_indexes(variable_index) in their order (:286-296).  quotient: len/2 elements. */
+int mle_compute_quotient_remainder(fq_t *quotient, mle_t *remainder, const mle_t *m, const fq_t *divisor, size_t var) {
+    if (var >= mle_num_vars(m)) return ORC_E_POINTS_LEN; /* Rust: subtract-with-overflow panic in get_y1_y2_indexes */
+    idx_pair_t *pairs = get_y1_y2_indexes(m, var); /* :283 */
+    if (!pairs) return ORC_E_ALLOC;
+    int rc = mle_partially_evaluate(remainder, m, var, divisor); /* :285 */
+    if (!rc)
+        for (size_t k = 0; k < m->len / 2; ++k) fq_sub(&quotient[k], &m->ev[pairs[k].y2], &m->ev[pairs[k].y1]); /* y2 - y1, :294 */
+    free(pairs);
+    return rc;
+}
+
 int mle_evaluate(mle_t *out, const mle_t *m, const opt_fq_t *pts, size_t npts) {
     if (npts != mle_num_vars(m)) return ORC_E_POINTS_LEN; /* :197-199 */
     mle_t acc;

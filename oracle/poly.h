@@ -42,6 +42,8 @@ int mle_evaluate(mle_t *out, const mle_t *m, const opt_fq_t *pts, size_t npts); 
 void mle_to_bytes(uint8_t *out, const mle_t *m);                   /* :225-234, 32*len bytes */
 void mle_evaluation_sum(fq_t *out, const mle_t *m);                /* :236-238 */
 int mle_scalar_mul(mle_t *out, const mle_t *m, const fq_t *s);     /* :151-153 */
+int mle_minus(mle_t *out, const mle_t *m, const fq_t *other);      /* :260-272 */
+int mle_compute_quotient_remainder(fq_t *quotient, mle_t *remainder, const mle_t *m, const fq_t *divisor, size_t var); /* :280-301 */
 int mle_add(mle_t *out, const mle_t *a, const mle_t *b);           /* :241-258 */
 int mle_w_add(mle_t *out, const mle_t *wb, const mle_t *wc);       /* :303-308 */
 int mle_w_mul(mle_t *out, const mle_t *self, const mle_t *other);  /* :310-312 */

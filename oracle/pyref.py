@@ -175,6 +175,18 @@ def partially_evaluate(table, var, r):
     return [(table[a] + (table[b] - table[a]) * r) % P for a, b in y1_y2_indexes(len(table), var)]
 
 
+def minus(table, v):
+    """minus (evaluation_form.rs:260-272)"""
+    return [(x - v) % P for x in table]
+
+
+def compute_quotient_remainder(table, divisor, var):
+    """compute_quotient_remainder (evaluation_form.rs:280-301) -> (quotient list, remainder table)"""
+    _check_pow2(len(table))
+    quotient = [(table[b] - table[a]) % P for a, b in y1_y2_indexes(len(table), var)]
+    return quotient, partially_evaluate(table, var, divisor)
+
+
 def evaluate(table, points):
     _check_pow2(len(table))
     if len(points) != num_vars(table):

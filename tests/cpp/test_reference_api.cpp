@@ -48,6 +48,18 @@ static void test_partially_evaluate_incomplete_points() { // evaluation_form.rs:
     CHECK(panics_with(ZK_E_POINTS_LEN, [&] { q.evaluate({Fq(1), Fq(2)}); })); // :197-199
     CHECK(panics_with(ZK_E_NOT_POW2, [&] { MLE bad(F({1, 2, 3})); }));        // :23-27
 }
+static void test_quotient_remainder() { // evaluation_form.rs:280-301 on the fold vector of :385-405, and the KZG division chain
+    MLE p(F(POLY4));
+    auto [q, r] = p.compute_quotient_remainder(Fq(4), 0);
+    CHECK(eq(r.get_evaluation_points(), {0, 0, 12, 12, 20, 24, 32, 36}));
+    CHECK(eq(q, {0, 0, 3, 3, 5, 5, 8, 8}));
+    // kzg/src/multilinear/prover.rs:59-96: (f - f(a)) divided by every (x_i - a_i) leaves 0
+    const std::vector<Fq> a = {Fq(4), Fq(2), Fq(6), Fq(1)};
+    MLE dividend = p.minus(Fq(120));
+    for (const Fq& ai : a) dividend = dividend.compute_quotient_remainder(ai, 0).second;
+    CHECK(eq(dividend.get_evaluation_points(), {0}));
+    CHECK(panics_with(ZK_E_POINTS_LEN, [&] { p.compute_quotient_remainder(Fq(1), 4); }));
+}
 static void test_operation_ws() { // evaluation_form.rs:422-473
     MLE wb(F({0, 0, 0, 3})), wc(F({0, 0, 0, 2}));
     CHECK(eq(MLE::w_add(wb, wc).get_evaluation_points(), {0, 0, 0, 2, 0, 0, 0, 2, 0, 0, 0, 2, 3, 3, 3, 5}));
@@ -125,6 +137,7 @@ int main() {
     const std::pair<const char*, std::function<void()>> tests[] = {
         {"test_evaluate_4_variables", test_evaluate_4_variables},
         {"test_partially_evaluate_incomplete_points", test_partially_evaluate_incomplete_points},
+        {"test_quotient_remainder", test_quotient_remainder},
         {"test_operation_ws", test_operation_ws},
         {"test_transcript", test_transcript},
         {"test_full_sumcheck_pass", test_full_sumcheck_pass},

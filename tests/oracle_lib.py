@@ -176,6 +176,28 @@ def mle_partially_evaluate(table, var, r):
     return out[: table.shape[0] // 2]
 
 
+def mle_minus(table, v):
+    table = np.ascontiguousarray(table, dtype=np.uint64).reshape(-1, 4)
+    out = np.empty_like(table)
+    rc = lib().orc_mle_minus(ptr(table), C.c_size_t(table.shape[0]), ptr(np.ascontiguousarray(v, dtype=np.uint64)), ptr(out))
+    if rc:
+        raise ValueError(f"oracle error {rc}")
+    return out
+
+
+def mle_quotient_remainder(table, divisor, var):
+    """compute_quotient_remainder -> (quotient (len/2, 4), remainder (len/2, 4))"""
+    table = np.ascontiguousarray(table, dtype=np.uint64).reshape(-1, 4)
+    half = table.shape[0] // 2
+    q = np.empty((max(half, 1), 4), dtype=np.uint64)
+    r = np.empty((max(half, 1), 4), dtype=np.uint64)
+    rc = lib().orc_mle_quotient_remainder(ptr(table), C.c_size_t(table.shape[0]), ptr(np.ascontiguousarray(divisor, dtype=np.uint64)),
+                                          C.c_size_t(var), ptr(q), ptr(r))
+    if rc:
+        raise ValueError(f"oracle error {rc}")
+    return q[:half], r[:half]
+
+
 def mle_evaluate(table, points):
     """points: list of None | (4,) limb arrays"""
     table = np.ascontiguousarray(table, dtype=np.uint64).reshape(-1, 4)

@@ -430,3 +430,50 @@ def test_dma_gate_arguments():
     c.forms_used()
     m.round_sums()
     assert c.forms_used() == {"sums_reg"}
+
+
+# ---- compute_quotient_remainder / minus (evaluation_form.rs:260-301; the division step of kzg/src/multilinear/prover.rs:59-96)
+@pytest.mark.parametrize("log_n", [1, 2, 3, 6, 11, 16])
+def test_quotient_remainder_every_variable_vs_oracle(ctx, log_n):
+    n = 1 << log_n
+    t = O.ints_to_mont(rand_table(n, 500 + log_n)) if log_n <= 11 else O.gen_table(SEED + 71, 0, n)
+    m = MLE(t)
+    rng = random.Random(log_n)
+    variables = range(log_n) if log_n <= 6 else (0, 1, log_n // 2, log_n - 1)
+    for var in variables:
+        for dv in (0, 1, P - 1, rng.randrange(P)):
+            d = O.fq1(dv)
+            q, r = m.compute_quotient_remainder(d, var)
+            oq, orr = O.mle_quotient_remainder(t, d, var)
+            assert np.array_equal(q, oq), (var, dv)
+            assert np.array_equal(r.get_evaluation_points(), orr), (var, dv)
+            assert np.array_equal(r.get_evaluation_points(), m.partially_evaluate((var, d)).get_evaluation_points())
+    assert np.array_equal(m.get_evaluation_points(), t)   # &self: the dividend is left unmodified
+    with pytest.raises(zk_amd.ZkError) as ei:
+        m.compute_quotient_remainder(O.fq1(1), log_n)      # variable index out of range
+    assert ei.value.status == 2
+    v = O.fq1(rng.randrange(P))
+    assert np.array_equal(m.minus(v).get_evaluation_points(), O.mle_minus(t, v))
+
+
+def test_kzg_opening_division_chain_ends_in_zero(ctx):
+    """The loop of kzg/src/multilinear/prover.rs:59-96 on the device: f - f(a) divided by (x_i - a_i) one variable after
+    the other leaves remainder 0, and every step satisfies y1 = rem - a q, y2 = rem + (1 - a) q."""
+    rng = random.Random(5)
+    log_n = 10
+    t = O.gen_table(SEED + 72, 0, 1 << log_n)
+    f = MLE(t)
+    openings = [O.fq1(rng.randrange(P)) for _ in range(log_n)]
+    v = f.evaluate(openings).get_evaluation_points()[0]
+    dividend = f.minus(v)
+    odiv = O.mle_minus(t, v)
+    for a in openings:
+        q, rem = dividend.compute_quotient_remainder(a, 0)
+        oq, orem = O.mle_quotient_remainder(odiv, a, 0)
+        assert np.array_equal(q, oq) and np.array_equal(rem.get_evaluation_points(), orem)
+        cur = O.mont_to_ints(dividend.get_evaluation_points())
+        qi, ri, ai = O.mont_to_ints(q), O.mont_to_ints(orem), O.mont_to_ints(a)[0]
+        half = len(cur) // 2
+        assert all((ri[j] - ai * qi[j]) % P == cur[j] and (ri[j] + (1 - ai) * qi[j]) % P == cur[half + j] for j in range(half))
+        dividend, odiv = rem, orem
+    assert O.mont_to_ints(dividend.get_evaluation_points()) == [0]

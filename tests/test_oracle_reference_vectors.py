@@ -188,3 +188,29 @@ def test_gkr_sum_check():                       # gkr_protocol.rs:126-142
     assert not O.gkr_verify(M([2] + inputs[1:]), c, O.OTranscript(), proof)
     proof.tamper(1, 2)
     assert not O.gkr_verify(M(inputs), c, O.OTranscript(), proof)
+
+
+def test_quotient_remainder_and_minus_c_oracle_equals_python_oracle():
+    """compute_quotient_remainder / minus (evaluation_form.rs:260-301): the reference holds no vector for them (its KZG tests
+    run over BLS12-381 and check only the pairing), so the two independent restatements are checked against each other and
+    against the division identity f = remainder + (x_v - a) * quotient on the hypercube."""
+    import random
+
+    rng = random.Random(11)
+    for log_n in (1, 2, 3, 5, 8):
+        n = 1 << log_n
+        vals = [rng.randrange(O.P) for _ in range(n)]
+        t = O.ints_to_mont(vals)
+        for var in range(log_n):
+            a = rng.randrange(O.P)
+            q, r = O.mle_quotient_remainder(t, O.fq1(a), var)
+            pq, pr = O.pyref.compute_quotient_remainder(vals, a, var)
+            assert O.mont_to_ints(q) == pq and O.mont_to_ints(r) == pr
+            for k, (i1, i2) in enumerate(O.pyref.y1_y2_indexes(n, var)):
+                assert (pr[k] - a * pq[k]) % O.P == vals[i1] and (pr[k] + (1 - a) * pq[k]) % O.P == vals[i2]
+        v = rng.randrange(O.P)
+        assert O.mont_to_ints(O.mle_minus(t, O.fq1(v))) == O.pyref.minus(vals, v)
+    # the reference's own small fold vector (evaluation_form.rs:385-405) seen through the remainder
+    poly4 = [0, 0, 0, 0, 0, 4, 0, 4, 0, 0, 3, 3, 5, 9, 8, 12]
+    q, r = O.mle_quotient_remainder(O.ints_to_mont(poly4), O.fq1(4), 0)
+    assert O.mont_to_ints(r) == [0, 0, 12, 12, 20, 24, 32, 36] and O.mont_to_ints(q) == [0, 0, 3, 3, 5, 5, 8, 8]

@@ -58,6 +58,8 @@ SYMBOLS = [
     ("zk_mle_download_mont", C.c_int, [_VP, u64p]),
     ("zk_mle_to_le32", C.c_int, [_VP, u8p]),
     ("zk_mle_partially_evaluate", C.c_int, [_VP, C.c_size_t, u64p, C.POINTER(_VP)]),
+    ("zk_mle_quotient_remainder", C.c_int, [_VP, C.c_size_t, u64p, C.POINTER(_VP), C.POINTER(_VP)]),
+    ("zk_mle_minus", C.c_int, [_VP, u64p, C.POINTER(_VP)]),
     ("zk_mle_evaluate", C.c_int, [_VP, u8p, u64p, C.c_size_t, C.POINTER(_VP)]),
     ("zk_mle_evaluation_sum", C.c_int, [_VP, u64p]),
     ("zk_mle_round_sums", C.c_int, [_VP, u64p]),

@@ -60,6 +60,9 @@ int launch_multifold_wide(int m, const void* src, void* dst, size_t Lout, const 
                           int lds_below_log, int coop_below_log, int log_ob, void* partials, void* out, hipStream_t st,
                           const DmaGates& gates = DmaGates());
 void launch_fold_var(const void* src, void* dst, size_t n_out, int log_s, const uint64_t r[4], hipStream_t st);
+// quot[m] = y2 - y1, rem[m] = y1 + (y2 - y1) r over the pairs of variable v (log_s = n - 1 - v), as launch_fold_var
+void launch_quot_rem_var(const void* src, void* quot, void* rem, size_t n_out, int log_s, const uint64_t r[4], hipStream_t st);
+void launch_minus(const void* in, void* out, size_t n, const uint64_t v[4], hipStream_t st);
 void launch_reduce_partials(const void* partials, int nblocks, int ns, void* out, hipStream_t st);
 int launch_sum_all(const void* T, size_t n, void* partials, hipStream_t st);
 int launch_eval3(const void* const t[4], size_t half, void* partials, hipStream_t st);

@@ -655,6 +655,26 @@ __global__ void __launch_bounds__(kThreads) k_fold_var(const fq* __restrict__ sr
     }
 }
 
+// compute_quotient_remainder (evaluation_form.rs:280-301): the same pairing with a second output stream --
+// quotient[m] = y2 - y1 (:294), remainder[m] = y1 + (y2 - y1) * r = partially_evaluate((v, r)) (:285)
+__global__ void __launch_bounds__(kThreads) k_quot_rem_var(const fq* __restrict__ src, fq* __restrict__ quot, fq* __restrict__ rem, size_t n_out,
+                                                            int log_s, fq r) {
+    const size_t stride = (size_t)gridDim.x * kThreads;
+    const size_t s = (size_t)1 << log_s;
+    for (size_t m = (size_t)blockIdx.x * kThreads + threadIdx.x; m < n_out; m += stride) {
+        const size_t i = ((m >> log_s) << (log_s + 1)) | (m & (s - 1));
+        const fq y1 = fq_load(src + i), y2 = fq_load(src + i + s);
+        const fq d = fq_sub(y2, y1);
+        fq_store(quot + m, d);
+        fq_store(rem + m, fq_add(y1, fq_mul_uniform(d, r)));
+    }
+}
+// minus (evaluation_form.rs:260-272): out[i] = in[i] - v
+__global__ void __launch_bounds__(kThreads) k_minus(const fq* __restrict__ in, fq* __restrict__ out, size_t n, fq v) {
+    const size_t stride = (size_t)gridDim.x * kThreads;
+    for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride) fq_store(out + i, fq_sub(fq_load(in + i), v));
+}
+
 // ---- second stage: fold per-block partials (fixed order) ---------------------------------
 // out[s] = sum_b partials[b*ns + s], s < ns <= 3.  One block.
 __global__ void __launch_bounds__(kThreads) k_reduce_partials(const fq* __restrict__ partials, int nblocks, int ns, fq* __restrict__ out) {
@@ -1212,6 +1232,12 @@ int launch_multifold(int m, const void* src, void* dst, size_t Lout, const uint6
 }
 void launch_fold_var(const void* src, void* dst, size_t n_out, int log_s, const uint64_t r[4], hipStream_t st) {
     hipLaunchKernelGGL(k_fold_var, dim3(grid_for(n_out)), dim3(kThreads), 0, st, (const fq*)src, (fq*)dst, n_out, log_s, to_fq(r));
+}
+void launch_quot_rem_var(const void* src, void* quot, void* rem, size_t n_out, int log_s, const uint64_t r[4], hipStream_t st) {
+    hipLaunchKernelGGL(k_quot_rem_var, dim3(grid_for(n_out)), dim3(kThreads), 0, st, (const fq*)src, (fq*)quot, (fq*)rem, n_out, log_s, to_fq(r));
+}
+void launch_minus(const void* in, void* out, size_t n, const uint64_t v[4], hipStream_t st) {
+    hipLaunchKernelGGL(k_minus, dim3(grid_for(n)), dim3(kThreads), 0, st, (const fq*)in, (fq*)out, n, to_fq(v));
 }
 void launch_reduce_partials(const void* partials, int nblocks, int ns, void* out, hipStream_t st) {
     hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(kThreads), 0, st, (const fq*)partials, nblocks, ns, (fq*)out);

@@ -290,6 +290,55 @@ int zk_mle_partially_evaluate(const zk_mle* m, size_t var, const uint64_t r[4], 
     return ZK_OK;
 }
 
+// compute_quotient_remainder (evaluation_form.rs:280-301): one pass, two output streams
+int zk_mle_quotient_remainder(const zk_mle* m, size_t var, const uint64_t divisor[4], zk_mle** quotient_out, zk_mle** remainder_out) {
+    if (!m || !divisor || !quotient_out || !remainder_out) return ZK_E_ARG;
+    zk_ctx* c = m->ctx;
+    const unsigned nv = ilog2(m->len);
+    if (var >= nv) return ZK_E_POINTS_LEN; // get_y1_y2_indexes: `number_of_variables() - 1 - idx` underflows and panics
+    int rc = set_device(c);
+    if (rc) return rc;
+    zk_mle *q = nullptr, *r = nullptr;
+    if ((rc = new_mle(c, m->len / 2, &q))) return rc;
+    if ((rc = new_mle(c, m->len / 2, &r))) { zk_mle_free(q); return rc; }
+    {
+        ProfScope ps(c, ZK_K_FOLD, (uint64_t)m->len * 64); // 32 B per entry read, 2 x 16 B per entry written
+        zkk::launch_quot_rem_var(m->d, q->d, r->d, m->len / 2, (int)(nv - 1 - var), divisor, c->stream);
+    }
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) {
+        c->err = std::string("quotient_remainder: ") + hipGetErrorString(e);
+        zk_mle_free(q);
+        zk_mle_free(r);
+        return ZK_E_HIP;
+    }
+    prof_collect(c);
+    *quotient_out = q;
+    *remainder_out = r;
+    return ZK_OK;
+}
+
+// minus (evaluation_form.rs:260-272)
+int zk_mle_minus(const zk_mle* m, const uint64_t v[4], zk_mle** out) {
+    if (!m || !v || !out) return ZK_E_ARG;
+    zk_ctx* c = m->ctx;
+    int rc = set_device(c);
+    if (rc) return rc;
+    zk_mle* o = nullptr;
+    if ((rc = new_mle(c, m->len, &o))) return rc;
+    zkk::launch_minus(m->d, o->d, m->len, v, c->stream);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) {
+        c->err = std::string("minus: ") + hipGetErrorString(e);
+        zk_mle_free(o);
+        return ZK_E_HIP;
+    }
+    *out = o;
+    return ZK_OK;
+}
+
 int zk_mle_evaluate(const zk_mle* m, const uint8_t* has, const uint64_t* vals, size_t npts, zk_mle** out) {
     if (!m || !out || (npts && (!has || !vals))) return ZK_E_ARG;
     if (npts != ilog2(m->len)) return ZK_E_POINTS_LEN; // evaluation_form.rs:197-199

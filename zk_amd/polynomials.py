@@ -94,6 +94,17 @@ class MultiLinearPolynomial:
         check(lib().zk_mle_partially_evaluate(self.h, idx, _limbs(r).ctypes.data_as(u64p), C.byref(h)), self.ctx.h)
         return MultiLinearPolynomial(ctx=self.ctx, _handle=h)
 
+    def compute_quotient_remainder(self, divisor, variable_index: int):   # :280-301 -> (quotient values, remainder)
+        q, r = C.c_void_p(), C.c_void_p()
+        check(lib().zk_mle_quotient_remainder(self.h, variable_index, _limbs(divisor).ctypes.data_as(u64p), C.byref(q), C.byref(r)), self.ctx.h)
+        quotient = MultiLinearPolynomial(ctx=self.ctx, _handle=q)
+        return quotient.get_evaluation_points(), MultiLinearPolynomial(ctx=self.ctx, _handle=r)
+
+    def minus(self, other):                    # :260-272: F(x) - V
+        h = C.c_void_p()
+        check(lib().zk_mle_minus(self.h, _limbs(other).ctypes.data_as(u64p), C.byref(h)), self.ctx.h)
+        return MultiLinearPolynomial(ctx=self.ctx, _handle=h)
+
     def evaluate(self, points):                # :194-223, points: list of None | limbs
         has = np.array([0 if p is None else 1 for p in points] or [0], dtype=np.uint8)
         vals = np.zeros((max(len(points), 1), 4), dtype=np.uint64)
