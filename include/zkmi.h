@@ -87,8 +87,13 @@ int zk_transcript_sample_n_challenges(zk_transcript *t, size_t n, uint64_t *out_
 int zk_transcript_peek_digest(const zk_transcript *t, uint8_t out[32]);    /* Keccak256(all bytes so far) */
 
 /* ---- MultiLinearPolynomial (polynomials/src/multilinear_polynomial/evaluation_form.rs) */
-/* MultiLinearPolynomial::new :22-32 -- copies `len` elements host -> device. */
+/* MultiLinearPolynomial::new :22-32 -- copies `len` elements host -> device.  The limbs must be fully reduced (< p, as
+ * ark-ff keeps them): an upload with any entry >= p is refused with ZK_E_ARG (one extra sweep of the table; switch the
+ * check off with zk_ctx_set_validate(ctx, 0)).  zk_mle_wrap_device does not check -- call zk_mle_count_noncanonical on
+ * memory of unknown origin. */
 int zk_mle_upload_mont(zk_ctx *ctx, const uint64_t *limbs, size_t len, zk_mle **out);
+int zk_ctx_set_validate(zk_ctx *ctx, int on);                                /* default on */
+int zk_mle_count_noncanonical(const zk_mle *m, uint64_t *count_out);         /* entries >= p; 0 for a valid table */
 int zk_mle_upload_le32(zk_ctx *ctx, const uint8_t *bytes, size_t len, zk_mle **out);
 /* borrow `len` elements of device memory the caller owns (Montgomery limbs); never freed by the library */
 int zk_mle_wrap_device(zk_ctx *ctx, void *device_ptr, size_t len, zk_mle **out);
@@ -310,6 +315,13 @@ int zk_gkr_prove(zk_ctx *ctx, zk_circuit *circuit, zk_transcript *transcript, co
 int zk_gkr_verify(zk_ctx *ctx, zk_circuit *circuit, zk_transcript *transcript, const zk_mle *inputs,
                   const uint64_t *output_poly, size_t output_len, const uint64_t *w_evals, const uint64_t *claims,
                   const uint64_t *coeffs, int *ok_out);
+/* INHERITED LIMITATION.  Like the reference (verifier.rs:63-64: partial_verify starts from
+ * sumcheck_proofs[i].initial_claim_sum as sent), zk_gkr_verify takes every layer's claim from the proof: it never checks
+ * that layer 0's claim is output_poly(rho), nor that layer i's is alpha W_i(r_b) + beta W_i(r_c).  A prover can therefore
+ * absorb a false output_poly and still be accepted -- the default stays bit-compatible with the reference, callers that rely
+ * on soundness switch the binding on: with zk_ctx_set_gkr_strict_claims(ctx, 1) the verifier recomputes both and rejects
+ * a mismatch (honest proofs are accepted in both modes, with the same transcript). */
+int zk_ctx_set_gkr_strict_claims(zk_ctx *ctx, int on);                       /* default off */
 
 /* ---- tuning / measurement hooks (no reference counterpart) ---------------------------- */
 /* Rounds bound per device pass by the single-MLE prover (1..8, default 4) and the fold kernel

@@ -253,3 +253,68 @@ def test_gkr_config5_full_size():
     bad_in = inputs.get_evaluation_points().copy()
     bad_in[12345] = O.fq1(12345)
     assert not GKRVerifier.verify_proof(bad_in, circuit, zk_amd.Transcript(), proof)
+
+
+def test_strict_claims_close_the_inherited_binding_gap():
+    """The reference's verifier takes every layer's claim from the proof (gkr/src/verifier.rs:63-64), so a prover that absorbs
+    a FALSE output_poly but sum-checks the true relation is accepted.  Built here with the line-by-line dense flow of
+    prover.rs:24-154 and one changed line; zk_ctx_set_gkr_strict_claims(1) rejects it, honest proofs pass in both modes."""
+    from zk_amd import MultiLinearPolynomial, ProductPolynomial, SumPolynomial
+    from zk_amd.gkr import GKRProof, _limbs_le32
+    from zk_amd.sumcheck import SumcheckProver
+
+    ctx = zk_amd.Context(0)
+    circuit = mk(CIRCUIT_GKR, ctx)
+    inputs = O.ints_to_mont([1, 2, 3, 4, 5, 6, 7, 8])
+    honest = GKRProver.generate_proof(circuit, zk_amd.Transcript(), inputs)
+    for strict in (False, True):
+        ctx.set_gkr_strict_claims(strict)
+        vt = zk_amd.Transcript()
+        assert GKRVerifier.verify_proof(inputs, circuit, vt, honest)
+    # the forgery: the output polynomial sent (and absorbed) is not the circuit's output
+    tr = zk_amd.Transcript()
+    evals = circuit.evaluate_at_input(inputs)
+    running = Circuit.get_w_i(0, evals)
+    fake_out = running.get_evaluation_points().copy()
+    fake_out[0] = O.fq1(424242)
+    tr.append(MultiLinearPolynomial(fake_out, ctx=ctx).to_bytes())                 # prover.rs:46 with the false table
+    random_values = list(tr.sample_n_challenges(running.number_of_variables()))
+    w_evals, proofs = [], []
+    for layer_idx in range(circuit.get_layer_count()):
+        mul_abc, add_abc = circuit.get_mul_i(layer_idx), circuit.get_add_i(layer_idx)
+        nv = mul_abc.number_of_variables()
+        if layer_idx == 0:
+            pts = [random_values[i] if i < len(random_values) else None for i in range(nv)]
+            new_mul, new_add = mul_abc.evaluate(pts), add_abc.evaluate(pts)
+            claim = running.evaluate(random_values).get_evaluation_points()[0]      # the TRUE W_0 at rho: the sumcheck stays consistent
+        else:
+            h = len(random_values) // 2
+            r_b, r_c = random_values[:h], random_values[h:]
+            wb, wc = running.evaluate(r_b).get_evaluation_points()[0], running.evaluate(r_c).get_evaluation_points()[0]
+            tr.append(_limbs_le32(np.stack([wb, wc]), ctx))
+            alpha, beta = tr.sample_challenge(), tr.sample_challenge()
+            pb = [r_b[i] if i < h else None for i in range(nv)]
+            pc = [r_c[i] if i < h else None for i in range(nv)]
+            new_mul = mul_abc.evaluate(pb).scalar_mul(alpha) + mul_abc.evaluate(pc).scalar_mul(beta)
+            new_add = add_abc.evaluate(pb).scalar_mul(alpha) + add_abc.evaluate(pc).scalar_mul(beta)
+            w_evals.append((wb, wc))
+            two = MultiLinearPolynomial(np.stack([wb, wc]), ctx=ctx)
+            claim = MultiLinearPolynomial(np.concatenate([two.scalar_mul(alpha).get_evaluation_points()[0:1],
+                                                          two.scalar_mul(beta).get_evaluation_points()[1:2]]), ctx=ctx).evaluation_sum()
+        next_w = Circuit.get_w_i(layer_idx + 1, evals)
+        f = SumPolynomial([ProductPolynomial([new_mul, MultiLinearPolynomial.w_mul(next_w, next_w)]),
+                           ProductPolynomial([new_add, MultiLinearPolynomial.w_add(next_w, next_w)])])
+        proof, pts = SumcheckProver.generate_proof_for_partial_verify(claim, f, tr)
+        random_values, running = list(pts), next_w
+        proofs.append(proof)
+    forged = GKRProof(fake_out, w_evals, proofs)
+    ctx.set_gkr_strict_claims(False)
+    assert GKRVerifier.verify_proof(inputs, circuit, zk_amd.Transcript(), forged)          # the reference's verifier accepts the false output
+    oc = O.OCircuit(CIRCUIT_GKR)
+    ctx.set_gkr_strict_claims(True)
+    assert not GKRVerifier.verify_proof(inputs, circuit, zk_amd.Transcript(), forged)      # the bound verifier does not
+    # a later layer's claim replaced consistently is out of reach of a test this size; its binding is checked on the honest proof:
+    bad = GKRProver.generate_proof(circuit, zk_amd.Transcript(), inputs)
+    bad.w_polys_evals[0] = (O.fq1(3), bad.w_polys_evals[0][1])
+    assert not GKRVerifier.verify_proof(inputs, circuit, zk_amd.Transcript(), bad)
+    del oc

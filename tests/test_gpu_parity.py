@@ -1,6 +1,7 @@
 """GPU parity tests: the HIP path (through the C ABI of libzkmi.so) against the CPU oracle
 (oracle/liboracle.so) and the committed golden vectors.  Bit-exact: integer field arithmetic.
 Run on an MI355X:  python -m pytest tests -m gpu"""
+import ctypes as C
 import random
 
 import numpy as np
@@ -477,3 +478,26 @@ def test_kzg_opening_division_chain_ends_in_zero(ctx):
         assert all((ri[j] - ai * qi[j]) % P == cur[j] and (ri[j] + (1 - ai) * qi[j]) % P == cur[half + j] for j in range(half))
         dividend, odiv = rem, orem
     assert O.mont_to_ints(dividend.get_evaluation_points()) == [0]
+
+
+def test_upload_rejects_limbs_that_are_not_fully_reduced():
+    """Limbs >= p are outside the contract (the radix-2^28 accumulations size their carries for canonical operands): an
+    upload refuses them instead of proving garbage; wrap_device leaves the check to the caller."""
+    c = zk_amd.Context(0)
+    good = O.gen_table(SEED + 3, 0, 1 << 10)
+    p_limbs = np.array([(P >> (64 * k)) & (2**64 - 1) for k in range(4)], dtype=np.uint64)
+    for bad_entry in (p_limbs, np.full(4, 2**64 - 1, dtype=np.uint64)):
+        t = good.copy()
+        t[777] = bad_entry
+        with pytest.raises(zk_amd.ZkError) as ei:
+            MLE(t, ctx=c)
+        assert ei.value.status == 8
+    t = good.copy()
+    t[5] = np.array([(P - 1 >> (64 * k)) & (2**64 - 1) for k in range(4)], dtype=np.uint64)   # p - 1 as raw limbs: the largest valid entry
+    m = MLE(t, ctx=c)
+    n = C.c_uint64(99)
+    assert zk_amd.lib().zk_mle_count_noncanonical(m.h, C.byref(n)) == 0 and n.value == 0
+    c.set_validate(False)
+    t[9], t[10] = p_limbs, np.full(4, 2**64 - 1, dtype=np.uint64)
+    m2 = MLE(t, ctx=c)                       # accepted unchecked ...
+    assert zk_amd.lib().zk_mle_count_noncanonical(m2.h, C.byref(n)) == 0 and n.value == 2   # ... and the explicit check finds both

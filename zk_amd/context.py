@@ -60,6 +60,15 @@ class Context:
         """Degree-2 prover: nine-sum sweeps over >= 2^from_log quarter-entries use unreduced accumulation (negative: never)."""
         check(lib().zk_ctx_set_deg2_lazy_sums(self.h, from_log))
 
+    def set_validate(self, on: bool = True):
+        """Uploads of Montgomery limbs refuse entries >= p (default on)."""
+        check(lib().zk_ctx_set_validate(self.h, int(on)))
+
+    def set_gkr_strict_claims(self, on: bool = True):
+        """zk_gkr_verify also checks that every layer's claim is bound to the output polynomial / the previous layer
+        (the reference does not: gkr/src/verifier.rs:63-64).  Default off."""
+        check(lib().zk_ctx_set_gkr_strict_claims(self.h, int(on)))
+
     def set_dma_gates(self, sums_from_log: int = 27, wide_stream_from_log: int = 22, fold2_from_log: int = 22):
         """Size thresholds (log2 entries, 64 = never) of the LDS-DMA forms of the big passes.  Proof bytes do not depend on it."""
         check(lib().zk_ctx_set_dma_gates(self.h, sums_from_log, wide_stream_from_log, fold2_from_log))

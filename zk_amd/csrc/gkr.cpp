@@ -439,6 +439,7 @@ int zk_gkr_verify(zk_ctx* c, zk_circuit* ci, zk_transcript* tr, const zk_mle* in
     std::vector<uint64_t> rnd(4 * std::max<size_t>(k0, 1));
     for (unsigned i = 0; i < k0; ++i) zkh::store(&rnd[4 * i], tr->sample()); // :32-36
     size_t n_rnd = k0, coeff_off = 0;
+    Fq prev_wb = zkh::zero(), prev_wc = zkh::zero();
 
     for (size_t layer_idx = 0; layer_idx < L; ++layer_idx) {
         const LayerDev& Ly = ci->layers[L - 1 - layer_idx];
@@ -447,10 +448,28 @@ int zk_gkr_verify(zk_ctx* c, zk_circuit* ci, zk_transcript* tr, const zk_mle* in
         if (layer_idx == 0) {
             if (n_rnd != (size_t)k_out) return ZK_OK; // a proof whose output_poly does not fit the circuit: rejected
             build_eq(c, wt, k_out, rnd.data(), zkh::one(), eqs[0], eqs[1]); // :43
+            if (c->gkr_strict_claims) { // not in the reference: the output layer's claim must be output_poly(rho)
+                zk_mle* w0 = nullptr;
+                if ((rc = zk_mle_upload_mont(c, output_poly, output_len, &w0))) return rc;
+                std::vector<uint8_t> has(std::max<size_t>(k0, 1), 1);
+                zk_mle* e = nullptr;
+                rc = zk_mle_evaluate(w0, has.data(), rnd.data(), k0, &e);
+                zk_mle_free(w0);
+                if (rc) return rc;
+                uint64_t v[4];
+                rc = zk_mle_download_mont(e, v);
+                zk_mle_free(e);
+                if (rc) return rc;
+                if (zkh::load(v) != zkh::load(claims)) return ZK_OK;
+            }
         } else {
             if (n_rnd != 2 * (size_t)k_out) return ZK_E_LEN_MISMATCH; // the circuit's layers do not chain (the prover refuses it too)
             const Fq alpha = tr->sample(), beta = tr->sample(); // :45-46
             build_eq2(c, wt, k_out, rnd.data(), alpha, rnd.data() + 4 * k_out, beta, eqs); // :49-56
+            // not in the reference: this layer's claim must be alpha W(r_b) + beta W(r_c) of the values the last layer ended on
+            if (c->gkr_strict_claims &&
+                zkh::add(zkh::mul(alpha, prev_wb), zkh::mul(beta, prev_wc)) != zkh::load(claims + 4 * layer_idx))
+                return ZK_OK;
         }
         int ok = 0;
         uint64_t final_claim[4];
@@ -485,6 +504,8 @@ int zk_gkr_verify(zk_ctx* c, zk_circuit* ci, zk_transcript* tr, const zk_mle* in
         tr->append_fq(wc);
         const Fq fbc = zkh::add(zkh::mul(pe[0], zkh::add(wb, wc)), zkh::mul(pe[1], zkh::mul(wb, wc))); // :106-107
         if (fbc != zkh::load(final_claim)) return ZK_OK; // :111-113
+        prev_wb = wb;
+        prev_wc = wc;
         rnd = ch;
         n_rnd = rounds;
         coeff_off += rounds;

@@ -84,6 +84,8 @@ void launch_gather4(const void* const t[4], size_t n, void* out, hipStream_t st)
 // out[(t * L + j) * world + q] = in[(q * ntab + t) * L + j]: the ranks' gathered local tables (rank-major) -> the remaining
 // tables, entry j * world + q = rank q's entry j (the table is sharded on its LOW index bits)
 void launch_interleave(const void* in, void* out, int world, int ntab, size_t L, hipStream_t st);
+// *count_u64 (device, zeroed by the caller) += number of entries of T that are not fully reduced (>= p)
+void launch_count_noncanonical(const void* T, size_t n, void* count_u64, hipStream_t st);
 void launch_from_le32(const void* in, void* out, size_t n, hipStream_t st);
 void launch_to_le32(const void* in, void* out, size_t n, hipStream_t st);
 void launch_generate(void* out, uint64_t seed, uint64_t first, uint64_t step, size_t n, hipStream_t st);

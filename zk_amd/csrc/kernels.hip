@@ -995,6 +995,23 @@ __global__ void __launch_bounds__(kThreads) k_interleave(const fq* __restrict__ 
     }
 }
 
+// Contract check of a table handed over as Montgomery limbs: every entry must be fully reduced (< p), as ark-ff keeps them --
+// the unreduced accumulations (fq28_*) size their carry cadence for canonical operands.  count[0] += entries >= p.
+__global__ void __launch_bounds__(kThreads) k_count_noncanonical(const fq* __restrict__ T, size_t n, unsigned long long* __restrict__ count) {
+    const u32 p[8] = FQ_P_LIMBS;
+    unsigned bad = 0;
+    const size_t stride = (size_t)gridDim.x * kThreads;
+    for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride) {
+        const fq a = fq_load_stream(T + i);
+        u32 br = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) (void)__builtin_subc(a.v[j], p[j], br, &br);
+        bad += br ? 0u : 1u; // no borrow: a >= p
+    }
+    for (int off = 32; off > 0; off >>= 1) bad += __shfl_down(bad, off, 64);
+    if ((threadIdx.x & 63) == 0 && bad) atomicAdd(count, (unsigned long long)bad);
+}
+
 // ---- format conversion / generation ------------------------------------------------------
 // canonical little-endian 256-bit values (any value < 2^256) -> Montgomery table
 __global__ void __launch_bounds__(kThreads) k_from_le32(const fq* __restrict__ in, fq* __restrict__ out, size_t n) {
@@ -1335,6 +1352,9 @@ void launch_fold2_tables(const void* const s[4], void* const d[4], size_t outlen
 void launch_interleave(const void* in, void* out, int world, int ntab, size_t L, hipStream_t st) {
     hipLaunchKernelGGL(k_interleave, dim3(grid_for((size_t)world * ntab * L)), dim3(kThreads), 0, st, (const fq*)in, (fq*)out, (unsigned)world,
                        (unsigned)ntab, L);
+}
+void launch_count_noncanonical(const void* T, size_t n, void* count_u64, hipStream_t st) {
+    hipLaunchKernelGGL(k_count_noncanonical, dim3(grid_for(n)), dim3(kThreads), 0, st, (const fq*)T, n, (unsigned long long*)count_u64);
 }
 void launch_from_le32(const void* in, void* out, size_t n, hipStream_t st) {
     hipLaunchKernelGGL(k_from_le32, dim3(grid_for(n)), dim3(kThreads), 0, st, (const fq*)in, (fq*)out, n);

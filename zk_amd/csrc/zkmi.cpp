@@ -133,6 +133,21 @@ int zk_transcript_peek_digest(const zk_transcript* t, uint8_t out[32]) {
 }
 
 // ---- MLE --------------------------------------------------------------------------------------
+// number of entries that are not fully reduced (>= p)
+int zk_mle_count_noncanonical(const zk_mle* m, uint64_t* count_out) {
+    if (!m || !count_out) return ZK_E_ARG;
+    zk_ctx* c = m->ctx;
+    int rc = set_device(c);
+    if (rc) return rc;
+    HIPCHK(c, hipMemsetAsync(c->sums_dev, 0, sizeof(uint64_t), c->stream)); // the counter lives in device memory (atomics)
+    zkk::launch_count_noncanonical(m->d, m->len, c->sums_dev, c->stream);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(c->sums_host, c->sums_dev, sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    *count_out = c->sums_host[0];
+    return ZK_OK;
+}
+
 int zk_mle_upload_mont(zk_ctx* c, const uint64_t* limbs, size_t len, zk_mle** out) {
     if (!c || !limbs || !out) return ZK_E_ARG;
     int rc = set_device(c);
@@ -145,6 +160,18 @@ int zk_mle_upload_mont(zk_ctx* c, const uint64_t* limbs, size_t len, zk_mle** ou
         c->err = std::string("upload: ") + hipGetErrorString(e);
         zk_mle_free(m);
         return ZK_E_HIP;
+    }
+    if (c->validate_uploads) { // limbs >= p are outside the contract (zkmi.h): refuse them here instead of proving garbage
+        uint64_t bad = 0;
+        rc = zk_mle_count_noncanonical(m, &bad);
+        if (!rc && bad) {
+            c->err = "upload: " + std::to_string(bad) + " entries are not fully reduced Montgomery limbs (>= p)";
+            rc = ZK_E_ARG;
+        }
+        if (rc) {
+            zk_mle_free(m);
+            return rc;
+        }
     }
     *out = m;
     return ZK_OK;
@@ -1114,6 +1141,16 @@ int zk_ctx_set_deg2_lazy_sums(zk_ctx* c, int from_log) {
 int zk_ctx_set_deg2_rounds_per_pass(zk_ctx* c, int rounds) {
     if (!c || (rounds != 1 && rounds != 2)) return ZK_E_ARG;
     c->deg2_pairs = rounds == 2;
+    return ZK_OK;
+}
+int zk_ctx_set_validate(zk_ctx* c, int on) {
+    if (!c) return ZK_E_ARG;
+    c->validate_uploads = on != 0;
+    return ZK_OK;
+}
+int zk_ctx_set_gkr_strict_claims(zk_ctx* c, int on) {
+    if (!c) return ZK_E_ARG;
+    c->gkr_strict_claims = on != 0;
     return ZK_OK;
 }
 int zk_ctx_set_dma_gates(zk_ctx* c, int sums_from_log, int wide_stream_from_log, int fold2_from_log) {

@@ -78,6 +78,8 @@ struct zk_ctx {
     bool deg2_pairs = true;      // degree-2 prover: two rounds per device pass (k_sum9 / k_fold2x4_sum9)
     int lazy_group = 4;          // elements per register load buffer in k_multifold_lazy (2 or 4)
     zkk::DmaGates gates;         // size thresholds of the LDS-DMA forms (zk_ctx_set_dma_gates)
+    bool gkr_strict_claims = false; // zk_gkr_verify also binds every layer's claim (zk_ctx_set_gkr_strict_claims)
+    bool validate_uploads = true;   // zk_mle_upload_mont* reject limbs >= p (zk_ctx_set_validate)
     zk_comm* comm = nullptr;     // zk_comm_init_*: this context is rank `comm->rank` of a sharded prove
     void* work[2] = {nullptr, nullptr};
     size_t work_cap[2] = {0, 0}; // bytes
