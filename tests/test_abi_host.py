@@ -104,3 +104,16 @@ def test_host_mirror_precondition_errors():
         zk_amd.SumPolynomial([p4, p2])
     s = zk_amd.SumPolynomial([p4, p4])
     assert s.degree() == 2 and s.number_of_variables() == 2 and s.length() == 4
+
+
+def test_rust_sys_crate_is_in_step_with_the_header():
+    """rust/zkmi-sys/src/lib.rs is generated from include/zkmi.h (tools/gen_rust_sys.py); it cannot be compiled here (no
+    Rust toolchain), but it must declare exactly the functions the header declares, and be the generator's current output."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("gen_rust_sys", os.path.join(ROOT, "tools", "gen_rust_sys.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    text = open(os.path.join(ROOT, "rust", "zkmi-sys", "src", "lib.rs")).read()
+    assert sorted(re.findall(r"pub fn (zk_[a-z0-9_]+)\(", text)) == _declared_functions()
+    assert text == gen.generate(open(os.path.join(ROOT, "include", "zkmi.h")).read()), "run python3 tools/gen_rust_sys.py"
