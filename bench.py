@@ -53,7 +53,7 @@ def parse(argv=None):
     ap.add_argument("--wide-lds-below", type=int, default=17, help="wide passes with < 2^k outputs make their weights per workgroup in LDS")
     ap.add_argument("--tail-max-log", type=int, default=-1, help="tables of <= 2^k entries bind eight rounds per pass (0 = off, -1 = library default 16)")
     ap.add_argument("--tail-out-below", type=int, default=13, help="passes with < 2^k outputs use one wave per output")
-    ap.add_argument("--fold-variant", type=int, default=0, help="0 eq-weight inner product, 1 tree, 2 tree+double buffer")
+    ap.add_argument("--fold-variant", type=int, default=0, help="0 eq-weight inner product, 1 fold tree (cross-check form)")
     ap.add_argument("--deg2-rounds", type=int, default=0, help="degree-2 prover: rounds per device pass (1 or 2; 0 = library default, 2)")
     ap.add_argument("--gather-log", type=int, default=13, help="multi-GPU: local tables of <= 2^k entries are all-gathered and finished on every rank (-1 = sharded to the end)")
     ap.add_argument("--deg2-lazy-from", type=int, default=None, help="degree-2 prover: unreduced nine-sum accumulation from 2^k quarter-entries (negative = never)")

@@ -324,10 +324,10 @@ int zk_gkr_verify(zk_ctx *ctx, zk_circuit *circuit, zk_transcript *transcript, c
 int zk_ctx_set_gkr_strict_claims(zk_ctx *ctx, int on);                       /* default off */
 
 /* ---- tuning / measurement hooks (no reference counterpart) ---------------------------- */
-/* Rounds bound per device pass by the single-MLE prover (1..8, default 4) and the fold kernel
- * variant (passes of 5..8 rounds always use the wide kernel): 0 = inner product with eq weights, one reduction per output (default); 1 = fold tree;
- * 2 = fold tree with register double-buffering; 3 = as 0 with 2-element load groups; 4 / 5 / 6 = as 0 with a
- * rolling window of 8 / 4 / 16 element loads in flight per lane.  Proof bytes do not depend on either. */
+/* Rounds bound per device pass by the single-MLE prover on small tables (1..8, default 4; passes of 5..8 rounds always use
+ * the wide kernels) and the form of the passes of up to 4 rounds: 0 = ONE inner product with the eq weights and one
+ * Montgomery reduction per output (default); 1 = the fold tree, i.e. the reference's successive partially_evaluate calls
+ * statement by statement -- slower, kept as the independent cross-check.  Proof bytes do not depend on either. */
 int zk_ctx_set_fold_batch(zk_ctx *ctx, int rounds_per_pass, int variant);
 /* Passes over a LARGE table bind up to `rounds` variables at once (5..8, default 8; 0 = off): as many as leave
  * the folded table at least 2^min_log_out entries (default 16), when that is `rounds` itself or at least two more

@@ -157,8 +157,7 @@ def test_sumcheck_vs_oracle_random_full_range(ctx, log_n):
     assert ok == O.sumcheck_verify(table, oclaim, ocoeffs)
 
 
-@pytest.mark.parametrize("batch,db", [(1, 0), (1, 1), (1, 2), (2, 0), (2, 1), (2, 2), (2, 3), (3, 0), (3, 1), (3, 2), (3, 3), (4, 0), (4, 1), (4, 3),
-                                      (3, 4), (3, 5), (4, 4), (4, 5), (4, 6), (5, 0), (6, 0), (7, 0), (8, 0), (8, 1)])
+@pytest.mark.parametrize("batch,db", [(1, 0), (1, 1), (2, 0), (2, 1), (3, 0), (3, 1), (4, 0), (4, 1), (5, 0), (6, 0), (7, 0), (8, 0), (8, 1)])
 def test_sumcheck_every_fold_batch_setting_gives_the_same_proof(batch, db):
     """Rounds-per-pass batching is an execution schedule, not a protocol change: proofs are identical."""
     c = zk_amd.Context(0)
@@ -174,6 +173,8 @@ def test_sumcheck_every_fold_batch_setting_gives_the_same_proof(batch, db):
         assert np.array_equal(ch, och), (batch, db, log_n)
     with pytest.raises(zk_amd.ZkError):
         c.set_fold_batch(9, 0)
+    with pytest.raises(zk_amd.ZkError):
+        c.set_fold_batch(4, 2)   # the losing variants left the library (tools/fold_variants.hip)
 
 
 @pytest.mark.parametrize("max_log,out_below,fold_batch", [(20, 13, 4), (20, 3, 4), (20, 0, 4), (12, 13, 3), (20, 20, 2), (9, 13, 1), (20, 13, 8)])
@@ -370,7 +371,7 @@ def test_sumcheck_dma_sums_and_dma_wide_fold_vs_oracle(log_n, wide, min_log_out,
     proof, ch = zk_amd.SumcheckProver.generate_sumcheck_proof(poly, return_challenges=True)
     forms = c.forms_used()
     assert "sums_dma" in forms and ("wide_dma_stream" if stream_stores else "wide_dma") in forms, forms
-    assert not forms & {"wide_reg", "wide_lds", "coop", "wide_dma" if stream_stores else "wide_dma_stream"}, forms
+    assert not forms & {"wide_lds", "coop", "wide_dma" if stream_stores else "wide_dma_stream"}, forms
     oclaim, ocoeffs, och = O.sumcheck_prove(table) if log_n <= 16 else O.sumcheck_prove_fast(table)
     assert list(proof.initial_claim_sum) == list(oclaim)
     assert np.array_equal(proof.round_polys, ocoeffs)

@@ -4,6 +4,7 @@
 //   real : the library kernels
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -Izk_amd/csrc tools/mfbench.hip -o tools/mfbench
 #include "../zk_amd/csrc/kernels.hip"
+#include "fold_variants.hip"
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -259,7 +260,7 @@ int main(int argc, char** argv) {
                bytes / ms / 1e6);
     }
     for (int group : {4, 2, 108, 104}) {
-        float ms = timeit([&] { launch_multifold_lazy(4, group, src, dst, Lout, w28, 4, part, sums, 0); }, a, b);
+        float ms = timeit([&] { launch_multifold_lazy(4, src, dst, Lout, w28, 4, part, sums, 0); }, a, b);
         printf("real launch_multifold_lazy group %3d: %8.1f GB/s (%.3f ms)\n", group, bytes / ms / 1e6, ms);
     }
     u32* wbuf; CHK(hipMalloc(&wbuf, kWideWeightWords * 4));

@@ -37,8 +37,8 @@ class Context:
 
     def set_fold_batch(self, rounds_per_pass: int, variant: int = 0):
         """Tuning knob of the single-MLE prover (proof bytes do not depend on it).
-        rounds_per_pass 1..8 (5..8: the wide kernel); variant 0 = eq-weight inner product (default), 1 = fold tree,
-        2 = tree + double buffering, 3..6 = load-pipelining variants of 0."""
+        rounds_per_pass 1..8 (5..8: the wide kernels); variant 0 = eq-weight inner product (default), 1 = the fold tree
+        (the reference's successive partially_evaluate calls, kept as the independent cross-check)."""
         check(lib().zk_ctx_set_fold_batch(self.h, rounds_per_pass, variant))
 
     def set_wide_fold(self, rounds: int = 8, min_log_out: int = 16, lds_weights_below_log: int = 17):

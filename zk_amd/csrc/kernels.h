@@ -24,7 +24,7 @@ enum Form : unsigned {
     kFormSumsReg = 1u << 1,       // k_block_sums
     kFormWideDma = 1u << 2,       // k_multifold_wide_dma<false>
     kFormWideDmaStream = 1u << 3, // k_multifold_wide_dma<true> (streaming stores)
-    kFormWideReg = 1u << 4,       // k_multifold_wide
+    kFormWideReg = 1u << 4,       // (retired: the register-load wide pass lives in tools/fold_variants.hip)
     kFormWideLds = 1u << 5,       // k_multifold_wide_lds
     kFormCoop = 1u << 6,          // k_multifold_coop
     kFormFold2Dma = 1u << 7,      // m = 2 LDS-DMA fold of the degree-2 branch
@@ -43,17 +43,16 @@ struct DmaGates {
 // out[b] (b < 2^log_ob) = sum of the b-th contiguous block of T (L entries); partials is scratch
 int launch_block_sums(const void* T, size_t L, int log_ob, void* partials, void* out, hipStream_t st, const DmaGates& gates = DmaGates());
 // dst (Lout entries) = src (Lout << m entries) with its top m variables bound to r[0..m) (4 limbs each);
-// out[c] (c < 2^log_ob) = sum of the c-th contiguous block of dst.  db: register double-buffering.
-int launch_multifold(int m, const void* src, void* dst, size_t Lout, const uint64_t* r, int log_ob, bool db, void* partials, void* out,
-                     hipStream_t st);
+// out[c] (c < 2^log_ob) = sum of the c-th contiguous block of dst.  The fold tree (m <= kMaxLazyBatch).
+int launch_multifold(int m, const void* src, void* dst, size_t Lout, const uint64_t* r, int log_ob, void* partials, void* out, hipStream_t st);
 // the same pass as one inner product with the eq weights: w28[b*10 + j] = limb j (28 bits) of
 // eq(r, b) * 2^280 mod p, b < 2^m (b's most significant bit belongs to r[0])
-// group = elements per register load buffer (2 or 4)
-int launch_multifold_lazy(int m, int group, const void* src, void* dst, size_t Lout, const uint32_t* w28, int log_ob, void* partials,
-                          void* out, hipStream_t st);
+int launch_multifold_lazy(int m, const void* src, void* dst, size_t Lout, const uint32_t* w28, int log_ob, void* partials, void* out,
+                          hipStream_t st);
 // the same pass for 3 <= m <= kMaxFoldBatch: weights derived on the device from the challenges r[0..m); two24 = 2^24
 // (Montgomery).  Outputs below 2^lds_below_log entries: per workgroup in LDS (one launch); larger ones: by a one-workgroup
-// kernel into wbuf (device, kWideWeightWords u32), read as scalar loads.  partials must hold 2 * kMaxBlocks elements
+// kernel into wbuf (device, kWideWeightWords u32), read as scalar loads (blocks that are not whole 64-entry rows take the LDS
+// form whatever their size).  partials must hold kMaxBlocks elements
 static constexpr int kWideWeightWords = (1 << kMaxFoldBatch) * 10;
 // Outputs below 2^coop_below_log entries (m >= 6): one wave per output (k_multifold_coop); 0 = never.
 int launch_multifold_wide(int m, const void* src, void* dst, size_t Lout, const uint64_t* r, const uint64_t two24[4], void* wbuf,

@@ -151,9 +151,10 @@ __device__ __forceinline__ fq mf_tree(fq (&in)[1 << M], const Chal<M>& ch) {
     return in[0];
 }
 
-// src: Lout << M entries, dst: Lout entries.  DB: a second register buffer keeps the next step's
-// 2^M element loads in flight under the current step's arithmetic.
-template <int M, bool DB>
+// src: Lout << M entries, dst: Lout entries.  The fold TREE: statement by statement the M successive partially_evaluate calls
+// of the reference -- kept as the independent cross-check of the inner-product forms below (zk_ctx_set_fold_batch variant 1)
+// and as the m = 1 pass.
+template <int M>
 __global__ void __launch_bounds__(kThreads) k_multifold(const fq* __restrict__ src, fq* __restrict__ dst, size_t Lout, Chal<M> ch,
                                                          int log_ob, fq* __restrict__ partials) {
     const unsigned gpb = gridDim.x >> log_ob;
@@ -162,35 +163,12 @@ __global__ void __launch_bounds__(kThreads) k_multifold(const fq* __restrict__ s
     const size_t j0 = (size_t)c * Lb;
     const size_t stride = (size_t)gpb * kThreads;
     fq acc[1] = {fq_zero()};
-    size_t i = (size_t)wl * kThreads + threadIdx.x;
-    if (DB) {
-        fq A[1 << M], B[1 << M];
-        if (i < Lb) mf_load<M>(A, src, Lout, j0 + i);
-        while (i < Lb) {
-            size_t n = i + stride;
-            if (n < Lb) mf_load<M>(B, src, Lout, j0 + n);
-            asm volatile("" ::: "memory"); // keep the prefetch above the arithmetic
-            fq o = mf_tree<M>(A, ch);
-            fq_store(dst + j0 + i, o);
-            acc[0] = fq_add(acc[0], o);
-            i = n;
-            if (i >= Lb) break;
-            n = i + stride;
-            if (n < Lb) mf_load<M>(A, src, Lout, j0 + n);
-            asm volatile("" ::: "memory");
-            o = mf_tree<M>(B, ch);
-            fq_store(dst + j0 + i, o);
-            acc[0] = fq_add(acc[0], o);
-            i = n;
-        }
-    } else {
-        for (; i < Lb; i += stride) {
-            fq A[1 << M];
-            mf_load<M>(A, src, Lout, j0 + i);
-            fq o = mf_tree<M>(A, ch);
-            fq_store(dst + j0 + i, o);
-            acc[0] = fq_add(acc[0], o);
-        }
+    for (size_t i = (size_t)wl * kThreads + threadIdx.x; i < Lb; i += stride) {
+        fq A[1 << M];
+        mf_load<M>(A, src, Lout, j0 + i);
+        fq o = mf_tree<M>(A, ch);
+        fq_store(dst + j0 + i, o);
+        acc[0] = fq_add(acc[0], o);
     }
     block_sum_store<1>(acc, partials);
 }
@@ -275,58 +253,6 @@ __global__ void __launch_bounds__(kThreads) k_multifold_lazy(const fq* __restric
             acc1[0] = fq_add(acc1[0], o);
             i = n;
         }
-    }
-    block_sum_store<1>(acc1, partials);
-}
-
-// Rolling-window form of the same inner product: every lane keeps D element loads in flight at all
-// times (slot b % D is refilled with element b + D -- of the next output once b + D >= 2^M -- right after
-// it has been unpacked), so the loads in flight no longer drop to one register buffer while the other is
-// being multiplied, and the window, not 2 x G, sets the register cost.
-// one element of the window, unrolled at the source level (the optimizer re-rolls a #pragma unroll loop here)
-template <int M, int D, int B>
-struct RollStep {
-    static __device__ __forceinline__ void run(fq (&buf)[D], u64 (&acc)[20], const fq* __restrict__ src, size_t Lout, size_t cur, size_t nxt,
-                                               const W28<M>& W) {
-        constexpr int NB = 1 << M;
-        u32 l[10];
-        fq28_unpack(buf[B % D], l);
-        if constexpr (B + D < NB) buf[B % D] = fq_load_stream(src + (size_t)(B + D) * Lout + cur);
-        else buf[B % D] = fq_load_stream(src + (size_t)(B + D - NB) * Lout + nxt);
-        asm volatile("" ::: "memory"); // keep the refill where it is issued
-        fq28_mac_limbs(acc, l, W.w[B]);
-        if constexpr (B + 1 < NB) RollStep<M, D, B + 1>::run(buf, acc, src, Lout, cur, nxt, W);
-    }
-};
-
-template <int M, int D>
-__global__ void __launch_bounds__(kThreads) k_multifold_roll(const fq* __restrict__ src, fq* __restrict__ dst, size_t Lout, W28<M> W,
-                                                              int log_ob, fq* __restrict__ partials) {
-    constexpr int NB = 1 << M;
-    static_assert(NB % D == 0, "window must divide the batch");
-    const unsigned gpb = gridDim.x >> log_ob;
-    const unsigned c = blockIdx.x / gpb, wl = blockIdx.x % gpb;
-    const size_t Lb = Lout >> log_ob;
-    const size_t j0 = (size_t)c * Lb;
-    const size_t stride = (size_t)gpb * kThreads;
-    fq acc1[1] = {fq_zero()};
-    size_t i = (size_t)wl * kThreads + threadIdx.x;
-    fq buf[D];
-    if (i < Lb) {
-#pragma unroll
-        for (int s = 0; s < D; ++s) buf[s] = fq_load_stream(src + (size_t)s * Lout + j0 + i);
-    }
-    while (i < Lb) {
-        const size_t n = i + stride;
-        const size_t nn = n < Lb ? n : i; // past the end: re-read this output's elements (unused) -- keeps the loop branch-free
-        u64 acc[20];
-#pragma unroll
-        for (int k = 0; k < 20; ++k) acc[k] = 0;
-        RollStep<M, D, 0>::run(buf, acc, src, Lout, j0 + i, j0 + nn, W);
-        fq o = fq28_redc(acc);
-        fq_store(dst + j0 + i, o);
-        acc1[0] = fq_add(acc1[0], o);
-        i = n;
     }
     block_sum_store<1>(acc1, partials);
 }
@@ -472,60 +398,6 @@ __global__ void __launch_bounds__(kThreads) k_multifold_wide_dma(const fq* __res
         for (int k = 1; k < kThreads / 64; ++k) t = fq_add(t, red[k]);
         fq_store(&partials[blockIdx.x], t);
     }
-}
-
-template <bool BIG> // BIG: the output is beyond the caches: streaming stores
-__global__ void __launch_bounds__(kThreads) k_multifold_wide(const fq* __restrict__ src, fq* __restrict__ dst, size_t Lout,
-                                                              const u32* __restrict__ wts, int m, int log_ob, fq* __restrict__ partials) {
-    constexpr int G = 2;
-    const int ng = (1 << m) / G; // m >= 3: ng is even
-    const unsigned gpb = gridDim.x >> log_ob;
-    const unsigned c = blockIdx.x / gpb, wi = blockIdx.x % gpb;
-    const size_t Lb = Lout >> log_ob;
-    const size_t j0 = (size_t)c * Lb;
-    const unsigned stride = gpb * kThreads; // in-block indices fit 32 bits (the launcher checks): one register each
-    const size_t gstep = (size_t)G * Lout;
-    // the running sum of this lane's outputs lives in LDS: touched once per output (2^m elements apart), and the
-    // 8 registers it would hold are the difference between 3 and 4 waves per SIMD
-    __shared__ fq run[kThreads];
-    run[threadIdx.x] = fq_zero();
-    unsigned i = wi * kThreads + threadIdx.x;
-    fq A[G], B[G];
-    if (i < Lb) lazy_load<G>(A, src, Lout, j0 + i, 0);
-    while (i < Lb) {
-        const unsigned n = i + stride;
-        u64 acc[20];
-#pragma unroll
-        for (int k = 0; k < 20; ++k) acc[k] = 0;
-        const fq* __restrict__ p = src + j0 + i;
-        const u32* __restrict__ w = wts; // wave-uniform: scalar loads
-        for (int g = 0; g < ng; g += 2) {
-            lazy_load<G>(B, p + gstep, Lout, 0, 0);
-#pragma unroll
-            for (int b = 0; b < G; ++b) fq28_mac(acc, A[b], w + b * 10);
-            if (g + 2 < ng) lazy_load<G>(A, p + 2 * gstep, Lout, 0, 0);
-            else if (n < Lb) lazy_load<G>(A, src, Lout, j0 + n, 0);
-#pragma unroll
-            for (int b = 0; b < G; ++b) fq28_mac(acc, B[b], w + (G + b) * 10);
-            // carry after every 16 products (the bound fq28_redc is written for): every column back below 2^28; the top one
-            // keeps the overflow, which is tiny -- the whole sum is < 2^8 p^2.  Uniform branch.
-            if ((g & 6) == 6) {
-#pragma unroll
-                for (int k = 0; k < 19; ++k) {
-                    acc[k + 1] += acc[k] >> 28;
-                    acc[k] &= FQ28_MASK;
-                }
-            }
-            p += 2 * gstep;
-            w += 2 * G * 10;
-        }
-        fq o = fq28_redc(acc);
-        if (BIG) fq_store_stream(dst + j0 + i, o); else fq_store(dst + j0 + i, o);
-        run[threadIdx.x] = fq_add(run[threadIdx.x], o);
-        i = n;
-    }
-    fq acc1[1] = {run[threadIdx.x]};
-    block_sum_store<1>(acc1, partials);
 }
 
 // The same pass for SMALL outputs (below 2^19 entries: a few waves per CU, time set by each lane's serial chain and by
@@ -1119,12 +991,11 @@ int launch_block_sums(const void* T, size_t L, int log_ob, void* partials, void*
     return g;
 }
 template <int M>
-static int launch_multifold_m(const void* src, void* dst, size_t Lout, const uint64_t* r, int log_ob, bool db, void* partials, hipStream_t st) {
+static int launch_multifold_m(const void* src, void* dst, size_t Lout, const uint64_t* r, int log_ob, void* partials, hipStream_t st) {
     Chal<M> ch;
     for (int l = 0; l < M; ++l) ch.r[l] = to_fq(r + 4 * l);
     int g = grid_blocks(Lout >> log_ob, log_ob);
-    if (db) hipLaunchKernelGGL((k_multifold<M, true>), dim3(g), dim3(kThreads), 0, st, (const fq*)src, (fq*)dst, Lout, ch, log_ob, (fq*)partials);
-    else hipLaunchKernelGGL((k_multifold<M, false>), dim3(g), dim3(kThreads), 0, st, (const fq*)src, (fq*)dst, Lout, ch, log_ob, (fq*)partials);
+    hipLaunchKernelGGL((k_multifold<M>), dim3(g), dim3(kThreads), 0, st, (const fq*)src, (fq*)dst, Lout, ch, log_ob, (fq*)partials);
     return g;
 }
 template <int M, int G>
@@ -1136,51 +1007,18 @@ static int launch_multifold_lazy_m(const void* src, void* dst, size_t Lout, cons
     hipLaunchKernelGGL((k_multifold_lazy<M, G>), dim3(g), dim3(kThreads), 0, st, (const fq*)src, (fq*)dst, Lout, W, log_ob, (fq*)partials);
     return g;
 }
-template <int M, int D>
-static int launch_multifold_roll_m(const void* src, void* dst, size_t Lout, const uint32_t* w28, int log_ob, void* partials, hipStream_t st) {
-    W28<M> W;
-    for (int b = 0; b < (1 << M); ++b)
-        for (int j = 0; j < 10; ++j) W.w[b][j] = w28[b * 10 + j];
-    int g = grid_blocks(Lout >> log_ob, log_ob);
-    hipLaunchKernelGGL((k_multifold_roll<M, D>), dim3(g), dim3(kThreads), 0, st, (const fq*)src, (fq*)dst, Lout, W, log_ob, (fq*)partials);
-    return g;
-}
-int launch_multifold_lazy(int m, int group, const void* src, void* dst, size_t Lout, const uint32_t* w28, int log_ob, void* partials,
-                          void* out, hipStream_t st) {
+int launch_multifold_lazy(int m, const void* src, void* dst, size_t Lout, const uint32_t* w28, int log_ob, void* partials, void* out,
+                          hipStream_t st) {
     int g = 0;
-    const bool g2 = group == 2;
-    if (group >= 100 && m >= 3) { // rolling window of group - 100 loads
-        const int d = group - 100;
-        if (m == 3) g = d == 4 ? launch_multifold_roll_m<3, 4>(src, dst, Lout, w28, log_ob, partials, st)
-                               : launch_multifold_roll_m<3, 8>(src, dst, Lout, w28, log_ob, partials, st);
-        else if (m == 4) g = d == 4 ? launch_multifold_roll_m<4, 4>(src, dst, Lout, w28, log_ob, partials, st)
-                          : d == 16 ? launch_multifold_roll_m<4, 16>(src, dst, Lout, w28, log_ob, partials, st)
-                                    : launch_multifold_roll_m<4, 8>(src, dst, Lout, w28, log_ob, partials, st);
-        else return -1;
-        hipLaunchKernelGGL(k_reduce_groups, dim3(1 << log_ob), dim3(kThreads), 0, st, (const fq*)partials, g >> log_ob, (fq*)out);
-        return g;
-    }
-    if (group >= 100) group = 4;
     switch (m) {
         case 1: g = launch_multifold_lazy_m<1, 2>(src, dst, Lout, w28, log_ob, partials, st); break;
-        case 2: g = g2 ? launch_multifold_lazy_m<2, 2>(src, dst, Lout, w28, log_ob, partials, st)
-                       : launch_multifold_lazy_m<2, 4>(src, dst, Lout, w28, log_ob, partials, st); break;
-        case 3: g = g2 ? launch_multifold_lazy_m<3, 2>(src, dst, Lout, w28, log_ob, partials, st)
-                       : launch_multifold_lazy_m<3, 4>(src, dst, Lout, w28, log_ob, partials, st); break;
-        case 4: g = g2 ? launch_multifold_lazy_m<4, 2>(src, dst, Lout, w28, log_ob, partials, st)
-                       : launch_multifold_lazy_m<4, 4>(src, dst, Lout, w28, log_ob, partials, st); break;
+        case 2: g = launch_multifold_lazy_m<2, 4>(src, dst, Lout, w28, log_ob, partials, st); break;
+        case 3: g = launch_multifold_lazy_m<3, 4>(src, dst, Lout, w28, log_ob, partials, st); break;
+        case 4: g = launch_multifold_lazy_m<4, 4>(src, dst, Lout, w28, log_ob, partials, st); break;
         default: return -1;
     }
     hipLaunchKernelGGL(k_reduce_groups, dim3(1 << log_ob), dim3(kThreads), 0, st, (const fq*)partials, g >> log_ob, (fq*)out);
     return g;
-}
-// grid for the wide pass: up to 2 * kMaxBlocks workgroups (16 per CU: the kernel runs 4 waves per SIMD)
-static inline int grid_blocks_wide(size_t Lb, int log_ob) {
-    size_t per = (Lb + kThreads - 1) / kThreads;
-    size_t cap = (size_t)(2 * kMaxBlocks) >> log_ob; // 1x ... 8x kMaxBlocks measure the same (5.53 - 5.57 TB/s)
-    if (per > cap) per = cap;
-    if (per < 1) per = 1;
-    return (int)(per << log_ob);
 }
 int launch_multifold_wide(int m, const void* src, void* dst, size_t Lout, const uint64_t* r, const uint64_t two24[4], void* wbuf,
                           int lds_below_log, int coop_below_log, int log_ob, void* partials, void* out, hipStream_t st, const DmaGates& gates) {
@@ -1199,49 +1037,40 @@ int launch_multifold_wide(int m, const void* src, void* dst, size_t Lout, const 
         hipLaunchKernelGGL(k_reduce_groups, dim3(1 << log_ob), dim3(kThreads), 0, st, (const fq*)partials, g >> log_ob, (fq*)out);
         return g;
     }
-    if (lds_below_log > 0 && (lds_below_log >= 63 || Lout < ((size_t)1 << lds_below_log))) { // small output: weights per workgroup in LDS
+    // small outputs, and blocks that are not whole 64-entry rows (the LDS-DMA form needs them): weights per workgroup in LDS
+    const bool rows = ((Lout >> log_ob) % 64) == 0;
+    if (!rows || (lds_below_log > 0 && (lds_below_log >= 63 || Lout < ((size_t)1 << lds_below_log)))) {
         int g = grid_blocks(Lout >> log_ob, log_ob);
         g_forms |= kFormWideLds;
         hipLaunchKernelGGL(k_multifold_wide_lds, dim3(g), dim3(kThreads), 0, st, (const fq*)src, (fq*)dst, Lout, ch, m, log_ob, (fq*)partials);
         hipLaunchKernelGGL(k_reduce_groups, dim3(1 << log_ob), dim3(kThreads), 0, st, (const fq*)partials, g >> log_ob, (fq*)out);
         return g;
     }
+    // LDS-DMA streams (every large pass): 5.9 vs 5.5 TB/s for register loads at 2^28 entries; ring depth 3, 4, 6 alike.  The eq
+    // weights come from a one-workgroup kernel and are read as scalar loads.
     hipLaunchKernelGGL(k_eq_weights28, dim3(1), dim3(kThreads), 0, st, ch, m, (u32*)wbuf);
-    if (((Lout >> log_ob) % 64) == 0) { // LDS-DMA streams (every large pass): 5.9 vs 5.5 TB/s at 2^28 entries; ring depth 3, 4, 6 alike
-        // one group of 64 outputs per wave-step; at most 1024 workgroups = 4 per CU (at 2^28 entries: exactly 4 groups per wave)
-        size_t per = ((Lout >> log_ob) / 64 + 3) / 4, cap = (size_t)1024 >> log_ob;
-        if (per > cap) per = cap;
-        if (per < 1) per = 1;
-        const int g = (int)(per << log_ob);
-        g_forms |= stream_stores ? kFormWideDmaStream : kFormWideDma;
-        if (stream_stores)
-            hipLaunchKernelGGL((k_multifold_wide_dma<true, 4>), dim3(g), dim3(kThreads), 0, st, (const fq*)src, (fq*)dst, Lout, (const u32*)wbuf,
-                               m, log_ob, (fq*)partials);
-        else
-            hipLaunchKernelGGL((k_multifold_wide_dma<false, 4>), dim3(g), dim3(kThreads), 0, st, (const fq*)src, (fq*)dst, Lout, (const u32*)wbuf,
-                               m, log_ob, (fq*)partials);
-        hipLaunchKernelGGL(k_reduce_groups, dim3(1 << log_ob), dim3(kThreads), 0, st, (const fq*)partials, g >> log_ob, (fq*)out);
-        return g;
-    }
-    int g = grid_blocks_wide(Lout >> log_ob, log_ob);
-    g_forms |= kFormWideReg;
+    // one group of 64 outputs per wave-step; at most 1024 workgroups = 4 per CU (at 2^28 entries: exactly 4 groups per wave)
+    size_t per = ((Lout >> log_ob) / 64 + 3) / 4, cap = (size_t)1024 >> log_ob;
+    if (per > cap) per = cap;
+    if (per < 1) per = 1;
+    const int g = (int)(per << log_ob);
+    g_forms |= stream_stores ? kFormWideDmaStream : kFormWideDma;
     if (stream_stores)
-        hipLaunchKernelGGL(k_multifold_wide<true>, dim3(g), dim3(kThreads), 0, st, (const fq*)src, (fq*)dst, Lout, (const u32*)wbuf, m, log_ob,
+        hipLaunchKernelGGL((k_multifold_wide_dma<true, 4>), dim3(g), dim3(kThreads), 0, st, (const fq*)src, (fq*)dst, Lout, (const u32*)wbuf, m, log_ob,
                            (fq*)partials);
     else
-        hipLaunchKernelGGL(k_multifold_wide<false>, dim3(g), dim3(kThreads), 0, st, (const fq*)src, (fq*)dst, Lout, (const u32*)wbuf, m, log_ob,
+        hipLaunchKernelGGL((k_multifold_wide_dma<false, 4>), dim3(g), dim3(kThreads), 0, st, (const fq*)src, (fq*)dst, Lout, (const u32*)wbuf, m, log_ob,
                            (fq*)partials);
     hipLaunchKernelGGL(k_reduce_groups, dim3(1 << log_ob), dim3(kThreads), 0, st, (const fq*)partials, g >> log_ob, (fq*)out);
     return g;
 }
-int launch_multifold(int m, const void* src, void* dst, size_t Lout, const uint64_t* r, int log_ob, bool db, void* partials, void* out,
-                     hipStream_t st) {
+int launch_multifold(int m, const void* src, void* dst, size_t Lout, const uint64_t* r, int log_ob, void* partials, void* out, hipStream_t st) {
     int g = 0;
     switch (m) {
-        case 1: g = launch_multifold_m<1>(src, dst, Lout, r, log_ob, db, partials, st); break;
-        case 2: g = launch_multifold_m<2>(src, dst, Lout, r, log_ob, db, partials, st); break;
-        case 3: g = launch_multifold_m<3>(src, dst, Lout, r, log_ob, db, partials, st); break;
-        case 4: g = launch_multifold_m<4>(src, dst, Lout, r, log_ob, false, partials, st); break;
+        case 1: g = launch_multifold_m<1>(src, dst, Lout, r, log_ob, partials, st); break;
+        case 2: g = launch_multifold_m<2>(src, dst, Lout, r, log_ob, partials, st); break;
+        case 3: g = launch_multifold_m<3>(src, dst, Lout, r, log_ob, partials, st); break;
+        case 4: g = launch_multifold_m<4>(src, dst, Lout, r, log_ob, partials, st); break;
         default: return -1;
     }
     hipLaunchKernelGGL(k_reduce_groups, dim3(1 << log_ob), dim3(kThreads), 0, st, (const fq*)partials, g >> log_ob, (fq*)out);

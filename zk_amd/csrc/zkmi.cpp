@@ -509,9 +509,9 @@ int fold_pass(const zk_ctx& k, const uint64_t two24[4], const void* src, void* d
     if (k.lazy && m >= 2) {
         uint32_t w28[(1 << zkk::kMaxLazyBatch) * 10];
         eq_weights28(r_mont, (unsigned)m, w28);
-        return zkk::launch_multifold_lazy(m, k.lazy_group, src, dst, lout, w28, m_next, partials, sums, stream);
+        return zkk::launch_multifold_lazy(m, src, dst, lout, w28, m_next, partials, sums, stream);
     }
-    return zkk::launch_multifold(m, src, dst, lout, r_mont, m_next, k.double_buffer, partials, sums, stream);
+    return zkk::launch_multifold(m, src, dst, lout, r_mont, m_next, partials, sums, stream);
 }
 } // namespace zki
 extern "C" {
@@ -1111,11 +1111,9 @@ int zk_sumcheck_verify_mle(zk_ctx* c, const zk_mle* poly, const uint64_t claim[4
 
 // ---- measurement ----------------------------------------------------------------------------------
 int zk_ctx_set_fold_batch(zk_ctx* c, int rounds_per_pass, int variant) {
-    if (!c || rounds_per_pass < 1 || rounds_per_pass > zkk::kMaxFoldBatch || variant < 0 || variant > 6) return ZK_E_ARG;
+    if (!c || rounds_per_pass < 1 || rounds_per_pass > zkk::kMaxFoldBatch || variant < 0 || variant > 1) return ZK_E_ARG;
     c->fold_batch = rounds_per_pass;
-    c->lazy = variant == 0 || variant >= 3;
-    c->lazy_group = variant == 3 ? 2 : variant == 4 ? 108 : variant == 5 ? 104 : variant == 6 ? 116 : 4;
-    c->double_buffer = variant == 2;
+    c->lazy = variant == 0;
     return ZK_OK;
 }
 int zk_ctx_set_wide_fold(zk_ctx* c, int rounds, int min_log_out, int lds_weights_below_log) {

@@ -71,12 +71,10 @@ struct zk_ctx {
     int tail_max_log = 16;       // tables of <= 2^k entries: eight rounds per pass with one wave per output (k_multifold_coop); 0: off
     int tail_out_below_log = 13; // ... used by passes whose output has fewer than 2^k entries
     int wide_min_log_out = 16;   // ... taken while its output keeps at least 2^wide_min_log_out entries
-    bool double_buffer = false;  // register double-buffering in k_multifold (tree variant)
-    bool lazy = true;            // inner-product form with one reduction per output (k_multifold_lazy)
+    bool lazy = true;            // inner-product form with one reduction per output (k_multifold_lazy); false: the fold tree
     int deg2_lazy_from_log = 18; // nine-sum sweeps over tables of >= 2^k quarter-entries accumulate unreduced (k_sum9_lazy); < 0: never
     uint64_t two24[4];           // 2^24 in Montgomery form (radix-2^28 reductions divide by 2^280, not 2^256)
     bool deg2_pairs = true;      // degree-2 prover: two rounds per device pass (k_sum9 / k_fold2x4_sum9)
-    int lazy_group = 4;          // elements per register load buffer in k_multifold_lazy (2 or 4)
     zkk::DmaGates gates;         // size thresholds of the LDS-DMA forms (zk_ctx_set_dma_gates)
     bool gkr_strict_claims = false; // zk_gkr_verify also binds every layer's claim (zk_ctx_set_gkr_strict_claims)
     bool validate_uploads = true;   // zk_mle_upload_mont* reject limbs >= p (zk_ctx_set_validate)
