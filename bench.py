@@ -57,6 +57,9 @@ def parse(argv=None):
     ap.add_argument("--deg2-rounds", type=int, default=0, help="degree-2 prover: rounds per device pass (1 or 2; 0 = library default, 2)")
     ap.add_argument("--gather-log", type=int, default=13, help="multi-GPU: local tables of <= 2^k entries are all-gathered and finished on every rank (-1 = sharded to the end)")
     ap.add_argument("--deg2-lazy-from", type=int, default=None, help="degree-2 prover: unreduced nine-sum accumulation from 2^k quarter-entries (negative = never)")
+    ap.add_argument("--wide-mfma", type=int, default=None, help="wide fold passes with >= 2^k outputs contract on the matrix cores (64 = never; default: library default)")
+    ap.add_argument("--wide-mfma-wg", type=int, default=2, help="workgroups per CU of the matrix-core wide fold")
+    ap.add_argument("--wide-mfma-depth", type=int, default=2, help="steps in flight per wave of the matrix-core wide fold (2..4)")
     ap.add_argument("--weak", action="store_true", help="multi-GPU: 2^log_n entries PER GPU instead of in total")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend of the ranks' rendezvous (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--shared-device", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
@@ -249,6 +252,8 @@ def apply_knobs(args, ctx):
         ctx.set_wide_fold(args.wide_batch, args.wide_min_log_out, args.wide_lds_below)
     if args.tail_max_log >= 0:
         ctx.set_tail_fold(args.tail_max_log, args.tail_out_below)
+    if args.wide_mfma is not None:
+        ctx.set_wide_mfma(args.wide_mfma, args.wide_mfma_wg, args.wide_mfma_depth)
     if args.deg2_rounds:
         ctx.set_deg2_rounds_per_pass(args.deg2_rounds)
     if args.deg2_lazy_from is not None:

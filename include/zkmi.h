@@ -352,11 +352,16 @@ int zk_ctx_set_deg2_lazy_sums(zk_ctx *ctx, int from_log);
  * m = 2 LDS-DMA passes from 2^fold2_from_log outputs per table (default 22).  The parity tests lower them so that the
  * kernels the benchmark numbers come from run on oracle-sized tables.  Proof bytes do not depend on any of it. */
 int zk_ctx_set_dma_gates(zk_ctx *ctx, int sums_from_log, int wide_stream_from_log, int fold2_from_log);
+/* Wide fold passes with at least 2^from_log outputs (64 = never) run their contraction on the matrix cores
+ * (v_mfma_i32_16x16x64_i8 over the raw table bytes and signed radix-256 digits of the eq weights) instead
+ * of the vector ALU; workgroups_per_cu (1..8) sizes its grid, depth (2..4) is the number of steps (4 KiB of table rows per
+ * wave each) kept in flight.  Proof bytes do not depend on it. */
+int zk_ctx_set_wide_mfma(zk_ctx *ctx, int from_log, int workgroups_per_cu, int depth);
 /* Which kernel forms the launches of the calling thread took since the last reset (bit mask, ZK_FORM_*): lets a test
  * assert that the form it forced is the one that ran. */
 enum { ZK_FORM_SUMS_DMA = 1 << 0, ZK_FORM_SUMS_REG = 1 << 1, ZK_FORM_WIDE_DMA = 1 << 2, ZK_FORM_WIDE_DMA_STREAM = 1 << 3,
        ZK_FORM_WIDE_REG = 1 << 4, ZK_FORM_WIDE_LDS = 1 << 5, ZK_FORM_COOP = 1 << 6, ZK_FORM_FOLD2_DMA = 1 << 7,
-       ZK_FORM_FOLD2_REG = 1 << 8, ZK_FORM_SUM9_LAZY = 1 << 9, ZK_FORM_SUM9 = 1 << 10, ZK_FORM_FOLD2_SUM9 = 1 << 11 };
+       ZK_FORM_FOLD2_REG = 1 << 8, ZK_FORM_SUM9_LAZY = 1 << 9, ZK_FORM_SUM9 = 1 << 10, ZK_FORM_FOLD2_SUM9 = 1 << 11, ZK_FORM_WIDE_MFMA = 1 << 12 };
 unsigned zk_ctx_forms_used(zk_ctx *ctx, int reset);
 enum { ZK_K_BLOCK_SUMS = 0, ZK_K_MULTIFOLD = 1, ZK_K_FOLD = 2, ZK_K_EVAL3 = 3, ZK_K_FOLD4_EVAL3 = 4, ZK_K_SUM9 = 5, ZK_K_FOLD2X4_SUM9 = 6, ZK_K_MULTIFOLD_WIDE = 7, ZK_K_MULTIFOLD_TAIL = 8,
        ZK_K_COUNT = 10 };

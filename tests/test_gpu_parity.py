@@ -502,3 +502,57 @@ def test_upload_rejects_limbs_that_are_not_fully_reduced():
     t[9], t[10] = p_limbs, np.full(4, 2**64 - 1, dtype=np.uint64)
     m2 = MLE(t, ctx=c)                       # accepted unchecked ...
     assert zk_amd.lib().zk_mle_count_noncanonical(m2.h, C.byref(n)) == 0 and n.value == 2   # ... and the explicit check finds both
+
+
+# ---- the wide pass on the matrix cores (k_multifold_wide_mfma): same field elements as every other form ------------------
+@pytest.mark.parametrize("log_n,wide,min_log_out,fold_batch", [(14, 6, 8, 2), (16, 8, 8, 2), (17, 8, 9, 3), (18, 8, 10, 4), (20, 8, 12, 4),
+                                                               (20, 7, 13, 4), (19, 5, 14, 2), (13, 5, 8, 2), (22, 8, 14, 4)])
+@pytest.mark.parametrize("stream_stores,wg_per_cu,depth", [(False, 2, 2), (True, 1, 3), (True, 1, 4)])
+def test_sumcheck_mfma_wide_fold_vs_oracle(log_n, wide, min_log_out, fold_batch, stream_stores, wg_per_cu, depth):
+    c = zk_amd.Context(0)
+    c.set_dma_gates(27, 0 if stream_stores else 64, 22)
+    c.set_wide_mfma(0, wg_per_cu, depth)
+    c.set_fold_batch(fold_batch, 0)
+    c.set_wide_fold(wide, min_log_out, 0)
+    c.set_tail_fold(0)
+    table = O.gen_table(SEED + 200 + log_n, 1, 1 << log_n)
+    poly = MLE(table, ctx=c)
+    c.forms_used()
+    proof, ch = zk_amd.SumcheckProver.generate_sumcheck_proof(poly, return_challenges=True)
+    forms = c.forms_used()
+    assert "wide_mfma" in forms and not forms & {"wide_dma", "wide_dma_stream", "wide_lds", "coop"}, forms
+    oclaim, ocoeffs, och = O.sumcheck_prove(table) if log_n <= 16 else O.sumcheck_prove_fast(table)
+    assert list(proof.initial_claim_sum) == list(oclaim)
+    assert np.array_equal(proof.round_polys, ocoeffs)
+    assert np.array_equal(ch, och)
+    if log_n <= 16:
+        pts = [r for r in ch]
+        assert np.array_equal(poly.evaluate(pts).get_evaluation_points(), O.mle_evaluate(table, pts))
+
+
+@pytest.mark.parametrize("fill", ["p-1", "zero", "one", "byte80", "byteff"])
+def test_mfma_wide_fold_on_extreme_bytes(fill):
+    """every table byte 0x80 / 0xff-ish / 0 (the signed-byte offset at its limits), every entry p - 1 (largest columns)"""
+    c = zk_amd.Context(0)
+    c.set_wide_mfma(0, 2)
+    c.set_fold_batch(2, 0)
+    c.set_wide_fold(8, 8, 0)
+    c.set_tail_fold(0)
+    n = 1 << 16
+    if fill == "p-1":
+        table = O.ints_to_mont([P - 1] * n)
+    elif fill == "zero":
+        table = np.zeros((n, 4), dtype=np.uint64)
+    elif fill == "one":
+        table = O.ints_to_mont([1] * n)
+    else:  # raw limbs (canonical: top byte below p's) with every other byte at the extreme
+        b = 0x80 if fill == "byte80" else 0xff
+        raw = int.from_bytes(bytes([b] * 31 + [0x2f]), "little")
+        assert raw < P
+        table = np.tile(np.array([(raw >> (64 * k)) & (2**64 - 1) for k in range(4)], dtype=np.uint64), (n, 1))
+    poly = MLE(table, ctx=c)
+    c.forms_used()
+    proof, ch = zk_amd.SumcheckProver.generate_sumcheck_proof(poly, return_challenges=True)
+    assert "wide_mfma" in c.forms_used()
+    oclaim, ocoeffs, och = O.sumcheck_prove(table)
+    assert list(proof.initial_claim_sum) == list(oclaim) and np.array_equal(proof.round_polys, ocoeffs) and np.array_equal(ch, och)

@@ -9,7 +9,7 @@ KERNELS = {"block_sums": 0, "multifold": 1, "fold": 2, "eval3": 3, "fold4_eval3"
 
 
 FORMS = ["sums_dma", "sums_reg", "wide_dma", "wide_dma_stream", "wide_reg", "wide_lds", "coop", "fold2_dma", "fold2_reg", "sum9_lazy", "sum9",
-         "fold2_sum9"]
+         "fold2_sum9", "wide_mfma"]
 
 
 class Context:
@@ -72,6 +72,11 @@ class Context:
     def set_dma_gates(self, sums_from_log: int = 27, wide_stream_from_log: int = 22, fold2_from_log: int = 22):
         """Size thresholds (log2 entries, 64 = never) of the LDS-DMA forms of the big passes.  Proof bytes do not depend on it."""
         check(lib().zk_ctx_set_dma_gates(self.h, sums_from_log, wide_stream_from_log, fold2_from_log))
+
+    def set_wide_mfma(self, from_log: int = 17, workgroups_per_cu: int = 2, depth: int = 2):
+        """Wide fold passes with >= 2^from_log outputs (64 = never) contract on the matrix cores; depth = steps in flight per
+        wave (2..4).  Proof bytes do not depend on it."""
+        check(lib().zk_ctx_set_wide_mfma(self.h, from_log, workgroups_per_cu, depth))
 
     def forms_used(self, reset: bool = True) -> set:
         """Names of the kernel forms launched from this thread since the last reset."""

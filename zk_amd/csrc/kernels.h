@@ -32,6 +32,7 @@ enum Form : unsigned {
     kFormSum9Lazy = 1u << 9,      // k_sum9_lazy
     kFormSum9 = 1u << 10,         // k_sum9<YSPLIT>
     kFormFold2Sum9 = 1u << 11,    // k_fold2_sum9 (fold fused with the next nine sums)
+    kFormWideMfma = 1u << 12,     // k_multifold_wide_mfma (the wide pass on the matrix cores)
 };
 extern thread_local unsigned g_forms;
 // Size thresholds of the LDS-DMA forms (log2 of entries; defaults = the measured break-even points)
@@ -39,6 +40,9 @@ struct DmaGates {
     int sums_from_log = 27;        // block sums by LDS-DMA from tables of 2^k entries
     int wide_stream_from_log = 22; // wide fold: streaming (nontemporal) stores from 2^k outputs
     int fold2_from_log = 22;       // degree-2 two-variable fold by LDS-DMA from 2^k outputs per table
+    int wide_mfma_from_log = 64;   // wide fold on the matrix cores (k_multifold_wide_mfma) from 2^k outputs; 64 = never
+    int wide_mfma_wg_per_cu = 2;   // its grid: workgroups per CU
+    int wide_mfma_depth = 2;       // its pipeline depth K (2..4): table rows of K steps in flight per wave
 };
 // out[b] (b < 2^log_ob) = sum of the b-th contiguous block of T (L entries); partials is scratch
 int launch_block_sums(const void* T, size_t L, int log_ob, void* partials, void* out, hipStream_t st, const DmaGates& gates = DmaGates());
@@ -53,7 +57,7 @@ int launch_multifold_lazy(int m, const void* src, void* dst, size_t Lout, const 
 // (Montgomery).  Outputs below 2^lds_below_log entries: per workgroup in LDS (one launch); larger ones: by a one-workgroup
 // kernel into wbuf (device, kWideWeightWords u32), read as scalar loads (blocks that are not whole 64-entry rows take the LDS
 // form whatever their size).  partials must hold kMaxBlocks elements
-static constexpr int kWideWeightWords = (1 << kMaxFoldBatch) * 10;
+static constexpr int kWideWeightWords = (1 << (kMaxFoldBatch - 1)) * 1024; // the matrix-core form's weight tiles (512 KiB); the scalar-load form uses 2^m x 10 words of it
 // Outputs below 2^coop_below_log entries (m >= 6): one wave per output (k_multifold_coop); 0 = never.
 int launch_multifold_wide(int m, const void* src, void* dst, size_t Lout, const uint64_t* r, const uint64_t two24[4], void* wbuf,
                           int lds_below_log, int coop_below_log, int log_ob, void* partials, void* out, hipStream_t st,

@@ -284,7 +284,9 @@ __device__ __forceinline__ fq chal_pick(const ChalWide& ch, int idx) { // ch.r[i
         if (idx == k) r = ch.r[k];
     return r;
 }
-__device__ __forceinline__ void eq_weights28_block(const ChalWide& ch, int m, u32* wout) {
+// thread b < 2^m of the workgroup gets eq(r, b) * 2^280 mod p as a plain integer (8 words, canonical); every thread of the
+// workgroup must call it (barriers inside)
+__device__ __forceinline__ fq eq_weight_of_thread(const ChalWide& ch, int m) {
     __shared__ fq half[2][16];
     const int mh = m >> 1, ml = m - mh; // 1 <= mh <= ml <= 4
     const int t = threadIdx.x & 15, side = (threadIdx.x >> 4) & 1;
@@ -309,9 +311,14 @@ __device__ __forceinline__ void eq_weights28_block(const ChalWide& ch, int m, u3
         }
         __syncthreads();
     }
+    if ((int)threadIdx.x < (1 << m)) return fq_mul(half[0][threadIdx.x >> ml], half[1][threadIdx.x & ((1 << ml) - 1)]);
+    return fq_zero();
+}
+__device__ __forceinline__ void eq_weights28_block(const ChalWide& ch, int m, u32* wout) {
+    const fq w = eq_weight_of_thread(ch, m);
     if ((int)threadIdx.x < (1 << m)) {
         u32 l28[10];
-        fq28_unpack(fq_mul(half[0][threadIdx.x >> ml], half[1][threadIdx.x & ((1 << ml) - 1)]), l28);
+        fq28_unpack(w, l28);
 #pragma unroll
         for (int j2 = 0; j2 < 10; ++j2) wout[threadIdx.x * 10 + j2] = l28[j2];
     }
@@ -454,6 +461,213 @@ __global__ void __launch_bounds__(kThreads) k_multifold_wide_lds(const fq* __res
         i = n;
     }
     block_sum_store<1>(acc1, partials);
+}
+
+// ---- the wide pass on the matrix cores ------------------------------------------------------------------------------------
+// T'[j] = sum_b W_b * T[b * L' + j] (W_b = eq(r, b) * 2^280 mod p) is a dense contraction once the operands are cut into BYTES:
+// column k (weight 256^k) of the unreduced product of output j is  sum_b sum_i T_b[j].byte[i] * W_b.digit[k - i]  -- a GEMM of
+// the RAW table bytes (row j, K index (b, i)) against a banded Toeplitz matrix of the weights' radix-256 digits, 64 columns
+// wide.  v_mfma_i32_16x16x64_i8 does 16 columns x 16 outputs x 64 K-values per instruction (16 cycles per SIMD): per 64-entry
+// row 8 matrix instructions replace the ~106 vector instructions of k_multifold_wide_dma, whose VALU issue co-limits that pass.
+// Signedness: the matrix cores multiply SIGNED bytes.  The weights are recoded once per pass into signed digits in [-128, 127]
+// (k_eq_weights_mfma); a table byte a is presented as a - 128 (one v_xor_b32 per four bytes).  Then
+//   sum a w = sum (a - 128) w + 128 sum w,
+// and the second term does not depend on the table: over all columns it is 128 * ((2^256 - 1) / 255) * sum_b W_b, and since
+// sum_b eq(r, b) = 1 that is a CONSTANT field element after the reduction.  The i32 accumulators start at beta = 2^27 (|column|
+// <= 256 * 32 * 2^14 = 2^27), so every column comes out non-negative; beta's contribution is a constant too.  Both are folded into
+// kfix = 128 (2^256 - 1)/255 - 2^27 ((2^512 - 1)/255) 2^-280 mod p, added to every output.  Exact integer arithmetic throughout:
+// the outputs are the same field elements as every other form of the pass.
+// Orientation: the weights are the A operand (M = product column), the table the B operand (N = output), so lane (g, n) of the
+// result holds columns 16 mt + 4 g + r of output (nt, n): the 64 columns of one output sit in the four lanes n, n+16, n+32, n+48,
+// which exchange 64-bit partial sums through LDS once per 64 outputs; one radix-2^28 Montgomery reduction per output, as before.
+// K index of lane group g, byte t of its 16-byte fragment: table row b = 2 bp + (g >> 1), byte i = 16 (g & 1) + t -- the 16 bytes
+// the lane reads from the row in LDS; the weight tiles are laid out to match (any K order works if A and B agree).
+typedef int v4i __attribute__((ext_vector_type(4)));
+static constexpr int kMfmaTileWords = 1024; // u32 per b-pair: 4 column tiles x 64 lanes x 4 words
+
+// tiles[((bp * 4 + mt) * 64 + lane) * 4 + u]: word u of lane's fragment of the weight tile (b-pair bp, columns 16 mt .. 16 mt + 15).
+// Every workgroup derives all 2^m weights (m/2 + 1 dependent products) and writes its share of the tiles.
+__global__ void __launch_bounds__(kThreads) k_eq_weights_mfma(ChalWide ch, int m, u32* __restrict__ tiles) {
+    __shared__ signed char dig[1 << kMaxFoldBatch][32];
+    const fq w = eq_weight_of_thread(ch, m);
+    if ((int)threadIdx.x < (1 << m)) { // signed radix-256 digits: the top byte of a canonical element is <= 0x30, so 32 digits do
+        int carry = 0;
+#pragma unroll
+        for (int idx = 0; idx < 32; ++idx) {
+            int v = (int)((w.v[idx >> 2] >> (8 * (idx & 3))) & 255u) + carry;
+            carry = v >= 128;
+            dig[threadIdx.x][idx] = (signed char)(v - (carry << 8));
+        }
+    }
+    __syncthreads();
+    const unsigned total = (1u << (m - 1)) * kMfmaTileWords;
+    for (unsigned idx = blockIdx.x * kThreads + threadIdx.x; idx < total; idx += gridDim.x * kThreads) {
+        const unsigned u = idx & 3, lane = (idx >> 2) & 63, mt = (idx >> 8) & 3, bp = idx >> 10;
+        const unsigned g = lane >> 4, row = lane & 15, b = 2 * bp + (g >> 1);
+        const int kg = (int)(16 * mt + row), i0 = (int)(16 * (g & 1) + 4 * u);
+        u32 word = 0;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int d = kg - (i0 + t);
+            const u32 byte = (d >= 0 && d < 32) ? (u32)(unsigned char)dig[b][d] : 0u;
+            word |= byte << (8 * t);
+        }
+        tiles[idx] = word;
+    }
+}
+
+// Schedule.  The four waves of a workgroup walk the b-pairs in LOCKSTEP, each on its own groups of 64 outputs, so the weight
+// tiles of a b-pair (4 KiB) are fetched once per workgroup: wave w brings tile mt = w by one LDS-DMA instruction into a shared
+// ring of three steps, its own two table rows (4 KiB) by four into its private ring of NP steps, and everything a wave waits
+// for is LDS-DMA in ONE in-order stream -- R(0) W(0) .. R(K-1) W(K-1) R(K) | step j: W(j+K) R(j+K+1) -- so the counted wait
+// before step s leaves R(s+1) .. R(s+K) and W(s+1) .. W(s+K-1) (5K - 1 instructions; two more with the stores of a group that
+// just ended) in flight.  One
+// s_barrier per step makes the other waves' weight tiles visible and protects the shared ring (a wave passes barrier s only
+// after every wave has finished reading step s-1).  A wave with fewer groups than its workgroup runs empty steps: the barrier
+// count is the same for all four.  A finished group's partial sums are exchanged through the table slot the step just freed.
+template <bool BIG, int K>
+__global__ void __launch_bounds__(kThreads) k_multifold_wide_mfma(const fq* __restrict__ src, fq* __restrict__ dst, size_t Lout,
+                                                                   const u32x4* __restrict__ tiles, int m, int log_ob, fq kfix,
+                                                                   fq* __restrict__ partials) {
+    constexpr int NP = K + 2, NW = K + 1; // step j issues W(j + K), R(j + K + 1)
+    __shared__ u32x4 ring[kThreads / 64][NP][2][128]; // per wave: NP steps x 2 table rows x 2 KiB
+    __shared__ u32x4 wring[NW][4][64];                // per workgroup: NW steps x 4 column tiles x 1 KiB
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = lane >> 4, n = lane & 15;
+    const unsigned gpb = gridDim.x >> log_ob;
+    const unsigned c = blockIdx.x / gpb, wi = blockIdx.x % gpb;
+    const size_t Lb = Lout >> log_ob, j0 = (size_t)c * Lb;
+    const unsigned ngroups = (unsigned)(Lb >> 6), gstride = gpb * (kThreads / 64);
+    const unsigned nbp = 1u << (m - 1);
+    const unsigned first = wi * (kThreads / 64); // the workgroup's first group: wave 0's, which has the most
+    const unsigned g0 = first + wave;
+    const unsigned mysteps = (g0 < ngroups ? (ngroups - g0 + gstride - 1) / gstride : 0) * nbp;
+    const unsigned wgsteps = (first < ngroups ? (ngroups - first + gstride - 1) / gstride : 0) * nbp;
+
+    auto issue_rows = [&](unsigned s) { // R(s): rows 2 bp, 2 bp + 1 of step s's group; four DMA instructions
+        const unsigned group = g0 + (s / nbp) * gstride, bp = s % nbp;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const u32x4* p = reinterpret_cast<const u32x4*>(src + (size_t)(2 * bp + r) * Lout + j0 + ((size_t)group << 6)) + lane;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
+                                             (__attribute__((address_space(3))) void*)&ring[wave][s % NP][r][0], 16, 0, 2);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p + 64),
+                                             (__attribute__((address_space(3))) void*)&ring[wave][s % NP][r][64], 16, 0, 2);
+        }
+    };
+    auto issue_tile = [&](unsigned s) { // W(s): this wave's quarter (column tile mt = wave) of step s's weight tiles; one DMA instruction
+        const u32x4* p = tiles + ((size_t)(s % nbp) * 4 + wave) * 64 + lane;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
+                                         (__attribute__((address_space(3))) void*)&wring[s % NW][wave][0], 16, 0, 0);
+    };
+
+    v4i acc[4][4];
+    fq run = fq_zero();
+#pragma unroll
+    for (int q = 0; q < K; ++q) {
+        if ((unsigned)q < mysteps) issue_rows(q);
+        if ((unsigned)q < wgsteps) issue_tile(q);
+    }
+    if ((unsigned)K < mysteps) issue_rows(K);
+    bool stored = false;
+    for (unsigned s = 0; s < wgsteps; ++s) {
+        const bool active = s < mysteps; // wave-uniform
+        if (active && s + K < mysteps) { // R(s+1) .. R(s+K) and W(s+1) .. W(s+K-1) may stay in flight: 5 K - 1 instructions
+            if (stored) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * K + 1) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * K - 1) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the last two steps of a wave, and empty steps: drain
+        }
+        stored = false;
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const unsigned bp = s % nbp;
+        v4i T[4], W[4];
+        if (active) {
+            if (bp == 0) {
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = v4i{1 << 27, 1 << 27, 1 << 27, 1 << 27}; // beta
+            }
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) { // the table operand: 16 outputs x (2 rows x 32 bytes) per tile, bytes presented as a - 128
+                const u32x4 raw = ring[wave][s % NP][g >> 1][2 * (16 * nt + n) + (g & 1)];
+                T[nt] = v4i{(int)(raw[0] ^ 0x80808080u), (int)(raw[1] ^ 0x80808080u), (int)(raw[2] ^ 0x80808080u), (int)(raw[3] ^ 0x80808080u)};
+            }
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const u32x4 w4 = wring[s % NW][mt][lane];
+                W[mt] = v4i{(int)w4[0], (int)w4[1], (int)w4[2], (int)w4[3]};
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // operands in registers before their slots are refilled
+        }
+        if (s + K < wgsteps) issue_tile(s + K);
+        const bool last = active && bp + 1 == nbp;
+        if (active && !last && s + K + 1 < mysteps) issue_rows(s + K + 1);
+        if (active) {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(W[mt], T[nt], acc[mt][nt], 0, 0, 0);
+        }
+        if (last) { // the group is complete: 64 columns per output, spread over four lanes -> one field element per lane
+            u64* x = reinterpret_cast<u64*>(&ring[wave][s % NP][0][0]); // the slot this step just read: 4 KiB of exchange space
+            u64 S[16];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) { // the 16 outputs of tile nt go to lane group g = nt
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) { // columns 16 mt + 4 g + r, r = 0..3: one 64-bit partial at word 4 mt + g
+                    const v4i a = acc[mt][nt];
+                    x[n * 17 + 4 * mt + g] = (u64)(u32)a[0] + ((u64)(u32)a[1] << 8) + ((u64)(u32)a[2] << 16) + ((u64)(u32)a[3] << 24);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // wave-private exchange: program order, no barrier
+                if (g == nt) {
+#pragma unroll
+                    for (int w = 0; w < 16; ++w) S[w] = x[n * 17 + w];
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            if (s + K + 1 < mysteps) issue_rows(s + K + 1); // the slot is free again
+            // V = sum_w S[w] 2^(32 w), S[w] < 2^53: 18 words, then 28-bit columns for the reduction
+            u32 v[18];
+            u64 cy = 0;
+#pragma unroll
+            for (int w = 0; w < 16; ++w) {
+                cy += S[w] & 0xffffffffull;
+                v[w] = (u32)cy;
+                cy = (cy >> 32) + (S[w] >> 32);
+            }
+            v[16] = (u32)cy;
+            v[17] = (u32)(cy >> 32);
+            u64 a28[20];
+#pragma unroll
+            for (int k = 0; k < 20; ++k) { // bits [28 k, 28 k + 28)
+                const int bit = 28 * k, wd = bit >> 5, sh = bit & 31;
+                const u64 two = (u64)v[wd] | (wd + 1 < 18 ? (u64)v[wd + 1] << 32 : 0);
+                a28[k] = (two >> sh) & FQ28_MASK;
+            }
+            const fq o = fq_add(fq28_redc(a28), kfix);
+            const unsigned group = g0 + (s / nbp) * gstride;
+            fq* out = dst + j0 + ((size_t)group << 6) + lane; // lane (g, n) holds output 16 g + n = lane
+            if (BIG) fq_store_stream(out, o); else fq_store(out, o);
+            stored = true;
+            run = fq_add(run, o);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const fq wsum = fq_wave_sum(run);
+    __syncthreads();
+    fq* red = reinterpret_cast<fq*>(&wring[0][0][0]);
+    if (lane == 0) red[wave] = wsum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        fq t = red[0];
+#pragma unroll
+        for (int k = 1; k < kThreads / 64; ++k) t = fq_add(t, red[k]);
+        fq_store(&partials[blockIdx.x], t);
+    }
 }
 
 // The same pass for TINY outputs (a few thousand entries or fewer: the tail of every prove).  With one lane per output
@@ -1043,6 +1257,28 @@ int launch_multifold_wide(int m, const void* src, void* dst, size_t Lout, const 
         int g = grid_blocks(Lout >> log_ob, log_ob);
         g_forms |= kFormWideLds;
         hipLaunchKernelGGL(k_multifold_wide_lds, dim3(g), dim3(kThreads), 0, st, (const fq*)src, (fq*)dst, Lout, ch, m, log_ob, (fq*)partials);
+        hipLaunchKernelGGL(k_reduce_groups, dim3(1 << log_ob), dim3(kThreads), 0, st, (const fq*)partials, g >> log_ob, (fq*)out);
+        return g;
+    }
+    if (gates.wide_mfma_from_log < 63 && Lout >= ((size_t)1 << std::max(gates.wide_mfma_from_log, 0))) {
+        // the contraction on the matrix cores: weight tiles by a small multi-workgroup kernel, then the LDS-DMA stream
+        const fq kfix = {{0xe5f7fc63u, 0xf613786fu, 0x795bc6d2u, 0xbe62fc84u, 0x799d7fdeu, 0xed6bec43u, 0x8c88f1adu, 0x164bcf99u}};
+        hipLaunchKernelGGL(k_eq_weights_mfma, dim3(1u << (m > 4 ? m - 4 : 0)), dim3(kThreads), 0, st, ch, m, (u32*)wbuf);
+        size_t per = ((Lout >> log_ob) / 64 + 3) / 4, cap = (size_t)(256 * gates.wide_mfma_wg_per_cu) >> log_ob;
+        if (per > cap) per = cap;
+        if (per < 1) per = 1;
+        const int g = (int)(per << log_ob);
+        g_forms |= kFormWideMfma;
+#define ZK_MFMA_LAUNCH(BIGV, KV)                                                                                                        \
+    hipLaunchKernelGGL((k_multifold_wide_mfma<BIGV, KV>), dim3(g), dim3(kThreads), 0, st, (const fq*)src, (fq*)dst, Lout, (const u32x4*)wbuf, m, \
+                       log_ob, kfix, (fq*)partials)
+        const int depth = gates.wide_mfma_depth;
+        if (stream_stores) {
+            if (depth == 2) ZK_MFMA_LAUNCH(true, 2); else if (depth == 3) ZK_MFMA_LAUNCH(true, 3); else ZK_MFMA_LAUNCH(true, 4);
+        } else {
+            if (depth == 2) ZK_MFMA_LAUNCH(false, 2); else if (depth == 3) ZK_MFMA_LAUNCH(false, 3); else ZK_MFMA_LAUNCH(false, 4);
+        }
+#undef ZK_MFMA_LAUNCH
         hipLaunchKernelGGL(k_reduce_groups, dim3(1 << log_ob), dim3(kThreads), 0, st, (const fq*)partials, g >> log_ob, (fq*)out);
         return g;
     }

@@ -1160,6 +1160,13 @@ int zk_ctx_set_dma_gates(zk_ctx* c, int sums_from_log, int wide_stream_from_log,
     c->gates.fold2_from_log = fold2_from_log;
     return ZK_OK;
 }
+int zk_ctx_set_wide_mfma(zk_ctx* c, int from_log, int workgroups_per_cu, int depth) {
+    if (!c || from_log < 0 || from_log > 64 || workgroups_per_cu < 1 || workgroups_per_cu > 8 || depth < 2 || depth > 4) return ZK_E_ARG;
+    c->gates.wide_mfma_from_log = from_log;
+    c->gates.wide_mfma_wg_per_cu = workgroups_per_cu;
+    c->gates.wide_mfma_depth = depth;
+    return ZK_OK;
+}
 unsigned zk_ctx_forms_used(zk_ctx* c, int reset) {
     (void)c; // the record is per host thread (a context is used from one thread at a time)
     const unsigned f = zkk::g_forms;
