@@ -50,7 +50,7 @@ def parse(argv=None):
     ap.add_argument("--fold-batch", type=int, default=0, help="rounds bound per device pass (0 = library default)")
     ap.add_argument("--wide-batch", type=int, default=-1, help="rounds bound by a pass over a large table (5..8, 0 = off, -1 = library default 8)")
     ap.add_argument("--wide-min-log-out", type=int, default=16, help="wide passes are taken while the folded table keeps >= 2^k entries")
-    ap.add_argument("--wide-lds-below", type=int, default=17, help="wide passes with < 2^k outputs make their weights per workgroup in LDS")
+    ap.add_argument("--wide-lds-below", type=int, default=15, help="wide passes with < 2^k outputs make their weights per workgroup in LDS")
     ap.add_argument("--tail-max-log", type=int, default=-1, help="tables of <= 2^k entries bind eight rounds per pass (0 = off, -1 = library default 16)")
     ap.add_argument("--tail-out-below", type=int, default=13, help="passes with < 2^k outputs use one wave per output")
     ap.add_argument("--fold-variant", type=int, default=0, help="0 eq-weight inner product, 1 fold tree (cross-check form)")
@@ -58,7 +58,7 @@ def parse(argv=None):
     ap.add_argument("--gather-log", type=int, default=13, help="multi-GPU: local tables of <= 2^k entries are all-gathered and finished on every rank (-1 = sharded to the end)")
     ap.add_argument("--deg2-lazy-from", type=int, default=None, help="degree-2 prover: unreduced nine-sum accumulation from 2^k quarter-entries (negative = never)")
     ap.add_argument("--wide-mfma", type=int, default=None, help="wide fold passes with >= 2^k outputs contract on the matrix cores (64 = never; default: library default)")
-    ap.add_argument("--wide-mfma-wg", type=int, default=2, help="workgroups per CU of the matrix-core wide fold")
+    ap.add_argument("--wide-mfma-wg", type=int, default=1, help="workgroups per CU of the matrix-core wide fold")
     ap.add_argument("--wide-mfma-depth", type=int, default=2, help="steps in flight per wave of the matrix-core wide fold (2..4)")
     ap.add_argument("--weak", action="store_true", help="multi-GPU: 2^log_n entries PER GPU instead of in total")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend of the ranks' rendezvous (nccl = RCCL; gloo for rehearsals)")
@@ -233,7 +233,7 @@ def main():
         "transport": result.get("transport"),
         "rccl_ranks": n_ranks if rccl else 0,
     }
-    for k in ("absorb_ms", "inclusive_ms", "kernels", "int32_alu", "survey_8d_equivalent", "proof_check", "extra"):
+    for k in ("absorb_ms", "inclusive_ms", "kernels", "kernel_forms", "int32_alu", "survey_8d_equivalent", "proof_check", "extra"):
         if k in result:
             out[k] = result[k]
     if not args.no_cpu_baseline and n_ranks == 1 and args.workload == "mle":
@@ -286,7 +286,7 @@ def mad_peak(ctx) -> float:
     return _mad_peak[key]
 
 
-def int32_alu(ctx, kernels):
+def int32_alu(ctx, kernels, forms):
     """The int32-ALU roofline beside the HBM one: limb multiply-adds per second of the two product-heavy kernels against the
     measured v_mad_u64_u32 issue ceiling of the chip, and which of the two rooflines binds each."""
     peak = mad_peak(ctx)
@@ -296,12 +296,21 @@ def int32_alu(ctx, kernels):
     alu = {"peak_lane_mads_per_s": peak,
            "peak_note": "k_mad_probe: 2048 x 256 lanes, four independent v_mad_u64_u32 chains per lane, measured in this run",
            "modmul_per_s_dependent_chain": modmul_per_s}
-    if "multifold_wide" in kernels:  # one 9x9-limb inner product (81 v_mad_u64_u32) per input entry
+    if "multifold_wide" in kernels:
         k = kernels["multifold_wide"]
         entries = k["alg_bytes_per_launch"] / 32.0 * 256 / 257
-        alu["fold_pass_limb_mads_per_s"] = 81 * entries / (k["avg_ms"] * 1e-3)
-        alu["fold_pass_frac"] = alu["fold_pass_limb_mads_per_s"] / peak
         alu["fold_pass_hbm_frac"] = hbm.get("multifold_wide")
+        if "wide_mfma" in forms:
+            # the contraction runs on the matrix cores: 64 product columns x 32 table bytes = 2048 i8 multiply-adds per entry (half of
+            # them against the zeros of the banded weight matrix), against the dense i8 MFMA peak (2 x the bf16 rate: 5 POP/s)
+            alu["fold_pass_pipe"] = "mfma_i8 (v_mfma_i32_16x16x64_i8)"
+            alu["fold_pass_i8_macs_per_s"] = 2048 * entries / (k["avg_ms"] * 1e-3)
+            alu["fold_pass_frac"] = alu["fold_pass_i8_macs_per_s"] / 2.5e15
+            alu["fold_pass_peak_note"] = "2.5e15 dense i8 multiply-adds per second (MI355X_MICROARCH.md: i8 = 2 x bf16 per clock)"
+        else:  # one 9x9-limb inner product (81 v_mad_u64_u32) per input entry
+            alu["fold_pass_pipe"] = "valu (v_mad_u64_u32)"
+            alu["fold_pass_limb_mads_per_s"] = 81 * entries / (k["avg_ms"] * 1e-3)
+            alu["fold_pass_frac"] = alu["fold_pass_limb_mads_per_s"] / peak
         alu["fold_pass_binds"] = "hbm" if hbm.get("multifold_wide", 0) >= alu["fold_pass_frac"] else "int32"
     if "sum9" in kernels:            # nine-sum sweeps: 18 field products per quarter-index (16 entries of 32 B), 82 limb products each
         k = kernels["sum9"]
@@ -351,6 +360,7 @@ def bench_single(args, ctx, zk_amd, np, workload, log_n, steps, warmup, absorb=F
         step()
     ctx.prof_enable(True)
     ctx.prof_reset()
+    ctx.forms_used()
     ctx.synchronize()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -361,6 +371,7 @@ def bench_single(args, ctx, zk_amd, np, workload, log_n, steps, warmup, absorb=F
     dt = time.perf_counter() - t0
     ctx.prof_enable(False)
     ms_per_step = dt * 1e3 / steps
+    forms = sorted(ctx.forms_used())
 
     kernels = read_kernels(ctx)
     if kernel == "multifold":  # the fold pass the time goes to: the wide pass over the full table when there is one
@@ -378,12 +389,12 @@ def bench_single(args, ctx, zk_amd, np, workload, log_n, steps, warmup, absorb=F
                 "fold4_eval3: 48 B per input entry per table; fold2x4_sum9: 32 B per input + 32 B per output entry per table; sum9 / block_sums: 32 B per entry)",
     }
     res = {
-        "elems_per_s": n / (ms_per_step * 1e-3), "ms_per_step": ms_per_step, "roofline": roofline, "kernels": kernels,
+        "elems_per_s": n / (ms_per_step * 1e-3), "ms_per_step": ms_per_step, "roofline": roofline, "kernels": kernels, "kernel_forms": forms,
         "config": {"workload": what, "log_n": log_n, "field": "BN254 Fq",
                    "parallelism": "1 GPU", "transcript": "Keccak-256 on host, one challenge per round"},
     }
     if want_alu:
-        res["int32_alu"] = int32_alu(ctx, kernels)
+        res["int32_alu"] = int32_alu(ctx, kernels, forms)
     if workload == "mle":
         # SURVEY.md 8(d) prices a whole prove at 128*N bytes (one fused fold + sum per round).  Batching rounds REMOVES
         # traffic (this build moves ~64*N), so that figure over the prove time exceeds what HBM delivers: it is reported

@@ -186,7 +186,7 @@ int zk_shard_fold(zk_shard *s, int m, const uint64_t *r_mont, int m_next, void *
  * src_dev (len elements, a power of two) with its top m variables bound at r_mont[0..m) (1 <= m <= 8), and
  * sums_dev_out (2^m_next elements, device; may be NULL when m_next = 0) = the block sums of dst_dev.  No context: the
  * pass runs on the calling thread's current device, asynchronously on hip_stream.  It calls no hipMalloc / hipFree /
- * allocating routine: its scratch (per-workgroup partial sums, the eq weights of a wide pass; 138 KiB) is a file-scope
+ * allocating routine: its scratch (per-workgroup partial sums, the weight tiles of a wide pass; 640 KiB) is a file-scope
  * __device__ array that every GPU the library runs on holds until the process ends.  len is limited to
  * 2^ZK_NOALLOC_MAX_LOG_LEN entries (ZK_E_TOO_LARGE beyond).  All calls on one GPU share that GPU's array: calls that
  * overlap on one GPU (two streams, two threads) race -- serialise them.  Pointers must be 16-byte aligned. */
@@ -332,7 +332,7 @@ int zk_ctx_set_fold_batch(zk_ctx *ctx, int rounds_per_pass, int variant);
 /* Passes over a LARGE table bind up to `rounds` variables at once (5..8, default 8; 0 = off): as many as leave
  * the folded table at least 2^min_log_out entries (default 16), when that is `rounds` itself or at least two more
  * than the default batch.  At 2^8 read streams per store stream the pass runs at the read-only HBM rate
- * (fold-pass ceiling).  lds_weights_below_log (default 17; 0 = never, 64 = always): wide passes with
+ * (fold-pass ceiling).  lds_weights_below_log (default 15; 0 = never, 64 = always): wide passes with
  * fewer than 2^k outputs derive their weights per workgroup in LDS (one launch, latency matters), larger ones
  * read them from a small device buffer as scalar loads (4 waves per SIMD).  Proof bytes do not depend on any of it. */
 int zk_ctx_set_wide_fold(zk_ctx *ctx, int rounds, int min_log_out, int lds_weights_below_log);
@@ -352,10 +352,10 @@ int zk_ctx_set_deg2_lazy_sums(zk_ctx *ctx, int from_log);
  * m = 2 LDS-DMA passes from 2^fold2_from_log outputs per table (default 22).  The parity tests lower them so that the
  * kernels the benchmark numbers come from run on oracle-sized tables.  Proof bytes do not depend on any of it. */
 int zk_ctx_set_dma_gates(zk_ctx *ctx, int sums_from_log, int wide_stream_from_log, int fold2_from_log);
-/* Wide fold passes with at least 2^from_log outputs (64 = never) run their contraction on the matrix cores
+/* Wide fold passes with at least 2^from_log outputs (default 15; 64 = never) run their contraction on the matrix cores
  * (v_mfma_i32_16x16x64_i8 over the raw table bytes and signed radix-256 digits of the eq weights) instead
  * of the vector ALU; workgroups_per_cu (1..8) sizes its grid, depth (2..4) is the number of steps (4 KiB of table rows per
- * wave each) kept in flight.  Proof bytes do not depend on it. */
+ * wave each) kept in flight (defaults 1 and 2).  Proof bytes do not depend on it. */
 int zk_ctx_set_wide_mfma(zk_ctx *ctx, int from_log, int workgroups_per_cu, int depth);
 /* Which kernel forms the launches of the calling thread took since the last reset (bit mask, ZK_FORM_*): lets a test
  * assert that the form it forced is the one that ran. */

@@ -362,8 +362,9 @@ def test_sumcheck_dma_sums_and_dma_wide_fold_vs_oracle(log_n, wide, min_log_out,
     claim, coefficients and challenges against the oracle, and the form that ran is the one forced."""
     c = zk_amd.Context(0)
     c.set_dma_gates(0, 0 if stream_stores else 64, 22)
+    c.set_wide_mfma(64)                    # the vector-ALU form of the large pass
     c.set_fold_batch(fold_batch, 0)
-    c.set_wide_fold(wide, min_log_out, 0)  # weights by scalar loads: the large-pass form
+    c.set_wide_fold(wide, min_log_out, 0)  # weights by scalar loads
     c.set_tail_fold(0)
     table = O.gen_table(SEED + 160 + log_n, 3, 1 << log_n)
     poly = MLE(table, ctx=c)
@@ -386,6 +387,7 @@ def test_dma_forms_on_worst_case_limbs():
     """every entry p - 1 (all radix-2^28 columns at their bound) through the DMA sums and the DMA wide fold"""
     c = zk_amd.Context(0)
     c.set_dma_gates(0, 0, 22)
+    c.set_wide_mfma(64)
     c.set_fold_batch(2, 0)
     c.set_wide_fold(8, 8, 0)
     c.set_tail_fold(0)

@@ -41,7 +41,7 @@ class Context:
         (the reference's successive partially_evaluate calls, kept as the independent cross-check)."""
         check(lib().zk_ctx_set_fold_batch(self.h, rounds_per_pass, variant))
 
-    def set_wide_fold(self, rounds: int = 8, min_log_out: int = 16, lds_weights_below_log: int = 17):
+    def set_wide_fold(self, rounds: int = 8, min_log_out: int = 16, lds_weights_below_log: int = 15):
         """Passes over a large table bind up to `rounds` (5..8; 0 = off) variables while the folded table keeps at least
         2^min_log_out entries; wide passes with fewer than 2^lds_weights_below_log outputs make their weights per
         workgroup in LDS, larger ones read them as scalar loads.  Proof bytes do not depend on it."""
@@ -73,7 +73,7 @@ class Context:
         """Size thresholds (log2 entries, 64 = never) of the LDS-DMA forms of the big passes.  Proof bytes do not depend on it."""
         check(lib().zk_ctx_set_dma_gates(self.h, sums_from_log, wide_stream_from_log, fold2_from_log))
 
-    def set_wide_mfma(self, from_log: int = 17, workgroups_per_cu: int = 2, depth: int = 2):
+    def set_wide_mfma(self, from_log: int = 15, workgroups_per_cu: int = 1, depth: int = 2):
         """Wide fold passes with >= 2^from_log outputs (64 = never) contract on the matrix cores; depth = steps in flight per
         wave (2..4).  Proof bytes do not depend on it."""
         check(lib().zk_ctx_set_wide_mfma(self.h, from_log, workgroups_per_cu, depth))

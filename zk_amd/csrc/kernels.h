@@ -40,8 +40,8 @@ struct DmaGates {
     int sums_from_log = 27;        // block sums by LDS-DMA from tables of 2^k entries
     int wide_stream_from_log = 22; // wide fold: streaming (nontemporal) stores from 2^k outputs
     int fold2_from_log = 22;       // degree-2 two-variable fold by LDS-DMA from 2^k outputs per table
-    int wide_mfma_from_log = 64;   // wide fold on the matrix cores (k_multifold_wide_mfma) from 2^k outputs; 64 = never
-    int wide_mfma_wg_per_cu = 2;   // its grid: workgroups per CU
+    int wide_mfma_from_log = 15;   // wide fold on the matrix cores (k_multifold_wide_mfma) from 2^k outputs; 64 = never
+    int wide_mfma_wg_per_cu = 1;   // its grid: workgroups per CU (1 and 2 measure alike; LDS admits two at depth 2)
     int wide_mfma_depth = 2;       // its pipeline depth K (2..4): table rows of K steps in flight per wave
 };
 // out[b] (b < 2^log_ob) = sum of the b-th contiguous block of T (L entries); partials is scratch

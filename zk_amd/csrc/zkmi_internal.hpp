@@ -67,7 +67,7 @@ struct zk_ctx {
     void* sums_host_dev = nullptr; // the device address of sums_host
     int fold_batch = 4;          // rounds bound per device pass (1..kMaxFoldBatch)
     int wide_batch = 8;          // rounds bound by a pass over a LARGE table (0: never; kernels.hip, k_multifold_wide) ...
-    int wide_lds_below_log = 17; // wide passes with fewer than 2^k outputs derive their weights per workgroup in LDS (one launch)
+    int wide_lds_below_log = 15; // wide passes with fewer than 2^k outputs derive their weights per workgroup in LDS (one launch)
     int tail_max_log = 16;       // tables of <= 2^k entries: eight rounds per pass with one wave per output (k_multifold_coop); 0: off
     int tail_out_below_log = 13; // ... used by passes whose output has fewer than 2^k entries
     int wide_min_log_out = 16;   // ... taken while its output keeps at least 2^wide_min_log_out entries
