@@ -64,7 +64,7 @@ def traffic_json(rd_dir, wr_dir, log_n):
     (the file bench.py reads for roofline.traffic)."""
     import json
 
-    names = {"k_multifold_lazy": "multifold", "k_multifold": "multifold", "k_multifold_roll": "multifold", "k_multifold_wide": "multifold_wide", "k_multifold_wide_lds": "multifold_wide", "k_multifold_wide_dma": "multifold_wide", "k_block_sums_dma": "block_sums", "k_multifold_coop": "multifold_tail", "k_block_sums": "block_sums",
+    names = {"k_multifold_lazy": "multifold", "k_multifold": "multifold", "k_multifold_roll": "multifold", "k_multifold_wide": "multifold_wide", "k_multifold_wide_lds": "multifold_wide", "k_multifold_wide_dma": "multifold_wide", "k_multifold_wide_mfma": "multifold_wide", "k_block_sums_dma": "block_sums", "k_multifold_coop": "multifold_tail", "k_block_sums": "block_sums",
              "k_sum9": "sum9", "k_fold2_tables": "fold2x4_sum9", "k_eval3": "eval3", "k_fold4_eval3": "fold4_eval3"}
     acc = defaultdict(lambda: {"launches": 0, "read_bytes": 0.0, "write_bytes": 0.0})
     for d, counter, key, scale in ((rd_dir, "FETCH_SIZE", "read_bytes", 2 * 1024.0), (wr_dir, "WRITE_SIZE", "write_bytes", 1024.0)):

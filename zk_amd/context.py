@@ -9,7 +9,7 @@ KERNELS = {"block_sums": 0, "multifold": 1, "fold": 2, "eval3": 3, "fold4_eval3"
 
 
 FORMS = ["sums_dma", "sums_reg", "wide_dma", "wide_dma_stream", "wide_reg", "wide_lds", "coop", "fold2_dma", "fold2_reg", "sum9_lazy", "sum9",
-         "fold2_sum9", "wide_mfma"]
+         "fold2_sum9", "wide_mfma", "sum9_mfma"]
 
 
 class Context:
@@ -68,6 +68,10 @@ class Context:
         """zk_gkr_verify also checks that every layer's claim is bound to the output polynomial / the previous layer
         (the reference does not: gkr/src/verifier.rs:63-64).  Default off."""
         check(lib().zk_ctx_set_gkr_strict_claims(self.h, int(on)))
+
+    def set_deg2_mfma_sums(self, from_log: int = 16):
+        """Degree-2 prover: nine-sum sweeps over >= 2^from_log quarter-entries run on the matrix cores (64 = never)."""
+        check(lib().zk_ctx_set_deg2_mfma_sums(self.h, from_log))
 
     def set_dma_gates(self, sums_from_log: int = 27, wide_stream_from_log: int = 22, fold2_from_log: int = 22):
         """Size thresholds (log2 entries, 64 = never) of the LDS-DMA forms of the big passes.  Proof bytes do not depend on it."""

@@ -33,6 +33,7 @@ enum Form : unsigned {
     kFormSum9 = 1u << 10,         // k_sum9<YSPLIT>
     kFormFold2Sum9 = 1u << 11,    // k_fold2_sum9 (fold fused with the next nine sums)
     kFormWideMfma = 1u << 12,     // k_multifold_wide_mfma (the wide pass on the matrix cores)
+    kFormSum9Mfma = 1u << 13,     // k_sum16_mfma (the nine sums on the matrix cores)
 };
 extern thread_local unsigned g_forms;
 // Size thresholds of the LDS-DMA forms (log2 of entries; defaults = the measured break-even points)
@@ -42,6 +43,7 @@ struct DmaGates {
     int fold2_from_log = 22;       // degree-2 two-variable fold by LDS-DMA from 2^k outputs per table
     int wide_mfma_from_log = 15;   // wide fold on the matrix cores (k_multifold_wide_mfma) from 2^k outputs; 64 = never
     int wide_mfma_wg_per_cu = 1;   // its grid: workgroups per CU (1 and 2 measure alike; LDS admits two at depth 2)
+    int sum9_mfma_from_log = 64;   // nine sums on the matrix cores (k_sum16_mfma) from 2^k quarter-entries; 64 = never
     int wide_mfma_depth = 2;       // its pipeline depth K (2..4): table rows of K steps in flight per wave
 };
 // out[b] (b < 2^log_ob) = sum of the b-th contiguous block of T (L entries); partials is scratch
@@ -72,11 +74,13 @@ int launch_eval3(const void* const t[4], size_t half, void* partials, hipStream_
 int launch_fold4_eval3(const void* const s[4], void* const d[4], size_t q, const uint64_t r[4], void* partials, hipStream_t st);
 void launch_fold4(const void* const s[4], void* const d[4], size_t half, const uint64_t r[4], hipStream_t st);
 // degree-2 branch, two rounds per pass (kernels.hip): out[3Y + t] (9 elements) = the nine sums of four tables of 4q
-// entries; partials must hold 18 * kMaxBlocks9 + 16 elements
+// entries; partials must hold kSum9PartialElems elements
 static constexpr int kMaxBlocks9 = 1024;
+static constexpr size_t kSum9PartialElems = (size_t)48 * kMaxBlocks9 + 64; // elements `partials` must hold for launch_sum9
 // fix24 = 2^24 (Montgomery); tables of at least 2^lazy_from_log quarter-entries take the unreduced-accumulation kernel
 // (lazy_from_log < 0: never)
-void launch_sum9(const void* const t[4], size_t q, const uint64_t fix24[4], int lazy_from_log, void* partials, void* out, hipStream_t st);
+void launch_sum9(const void* const t[4], size_t q, const uint64_t fix24[4], int lazy_from_log, void* partials, void* out, hipStream_t st,
+                 const DmaGates& gates = DmaGates());
 // bind the two top variables of four tables of 4*outlen entries (w28: the 4 eq weights as for launch_multifold_lazy)
 // into d[] (outlen entries each)
 // wbuf (device, >= 40 u32) and partials (>= 1024 elements) are scratch for the large-table form; either may be null (then never used)

@@ -1014,6 +1014,210 @@ __global__ void __launch_bounds__(576) k_sum9_lazy(Tab4 T, size_t q, fq fix24, f
     if (lane == 0) fq_store(&partials[((size_t)(term * 3 + B) * gridDim.x + blockIdx.x) * 3 + A], r);
 }
 
+// ---- the nine sums on the matrix cores ---------------------------------------------------------------------------------------
+// U[a][b] = sum_j F[a][b] G[a][b] with F[a][b], G[a][b] plain sums of the term's entries e = 2 b1 + b2 at quarter-index j, so every
+// U is a sum of the sixteen cross sums P[e][e'] = sum_j F_e[j] G_e'[j] (as integers of the stored limbs).  Cut into BYTES,
+//   P[e][e'] = sum_{i,i'} 256^(i+i') C[i][i'],   C[i][i'] = sum_j F_e[j].byte[i] * G_e'[j].byte[i'],
+// and C is a 32 x 32 x (number of j) matrix product with the contraction over j: v_mfma_i32_32x32x32_i8 takes 32 quarter-indices
+// per instruction.  Its operands want byte i of 16 consecutive entries per lane -- the transpose of the table's layout -- which
+// ds_read_b64_tr_b8 delivers from the entry-major LDS tile for free (per 16 lanes: 8 rows x 16 byte columns, column-major out;
+// tools/probe_tr8.hip).  Signed bytes: both operands are presented as byte - 128, and
+//   sum_j F G = sum_k 256^k D[k] + 128 c1 (A + B) - 2^14 c1^2 N,   D[k] = sum_{i+i'=k} C_signed[i][i'],  c1 = (2^256 - 1)/255,
+// with A = sum_j F_e[j], B = sum_j G_e'[j] (plain modular sums, one 256-bit add per entry) and N the number of j.  Exact integer
+// arithmetic: the sums are the same field elements as k_sum9 / k_sum9_lazy give.
+// Workgroup = 4 waves on one term; wave w keeps the four accumulators C[e = w][e' = 0..3] (64 registers) and the plain sums of
+// rows F_w and G_w; tiles of 64 quarter-indices (8 rows x 2 KiB) come through a three-tile LDS-DMA ring as in k_sum9_lazy.
+// partials: [(term * gridDim.x + bx) * 24 + ...]: 16 values P_signed[e][e'] * 2^-256 (index 4 e + e'), then A_e (4), then B_e' (4).
+#include "pow256_tab.inc"
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+__global__ void __launch_bounds__(kThreads) k_sum16_mfma(Tab4 T, size_t q, fq* __restrict__ partials) {
+    __shared__ u32x4 sh[3][8][128]; // three tiles x (F_0..F_3, G_0..G_3) x 64 entries x 32 B
+    const int term = blockIdx.y, lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const fq* __restrict__ F = T.t[2 * term];
+    const fq* __restrict__ G = T.t[2 * term + 1];
+    const size_t stride = (size_t)gridDim.x * 64, base0 = (size_t)blockIdx.x * 64;
+    const int nt = base0 < q ? (int)((q - base0 + stride - 1) / stride) : 0;
+    auto stage = [&](int t) { // wave w brings rows 2w, 2w + 1: four DMA instructions
+#pragma unroll
+        for (int r2 = 0; r2 < 2; ++r2) {
+            const int r = 2 * w + r2;
+            const fq* src = ((r & 4) ? G : F) + (size_t)(r & 3) * q + base0 + (size_t)t * stride;
+            const u32x4* p = reinterpret_cast<const u32x4*>(src) + lane;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
+                                             (__attribute__((address_space(3))) void*)&sh[t % 3][r][0], 16, 0, 2);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p + 64),
+                                             (__attribute__((address_space(3))) void*)&sh[t % 3][r][64], 16, 0, 2);
+        }
+    };
+    v16i acc[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc[e][k] = 0;
+    u32 sf[9], sg[9]; // plain sums of this lane's entries of rows F_w and G_w (value < 2^256 * tiles)
+#pragma unroll
+    for (int k = 0; k < 9; ++k) sf[k] = sg[k] = 0;
+    // transposed-read address of this lane inside a row: lane 16 gg + 2 qq + pp reads entry 16 (gg >> 1) + qq (+ 8 for the second
+    // read, + 32 for the second K step), bytes 16 (gg & 1) + 8 pp .. + 7
+    const int gg = lane >> 4, qq = (lane >> 1) & 7, pp = lane & 1;
+    const u32 tr_off = (u32)((16 * (gg >> 1) + qq) * 32 + 16 * (gg & 1) + 8 * pp);
+    if (nt > 0) stage(0);
+    if (nt > 1) stage(1);
+    for (int t = 0; t < nt; ++t) {
+        if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); // leaves tile t+1's four instructions in flight
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (t + 2 < nt) stage(t + 2);
+        const u32 tile = (u32)(uintptr_t)&sh[t % 3][0][0];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) { // 32 quarter-indices per step
+            const u32 a0 = tile + (u32)w * 2048u + (u32)ks * 1024u + tr_off; // row F_w
+            const u32 b0 = tile + 4u * 2048u + (u32)ks * 1024u + tr_off;      // rows G_0 .. G_3
+            u64 fa0, fa1, gb[4][2];
+            asm volatile(
+                "ds_read_b64_tr_b8 %0, %10\n\t"
+                "ds_read_b64_tr_b8 %1, %10 offset:256\n\t"
+                "ds_read_b64_tr_b8 %2, %11\n\t"
+                "ds_read_b64_tr_b8 %3, %11 offset:256\n\t"
+                "ds_read_b64_tr_b8 %4, %11 offset:2048\n\t"
+                "ds_read_b64_tr_b8 %5, %11 offset:2304\n\t"
+                "ds_read_b64_tr_b8 %6, %11 offset:4096\n\t"
+                "ds_read_b64_tr_b8 %7, %11 offset:4352\n\t"
+                "ds_read_b64_tr_b8 %8, %11 offset:6144\n\t"
+                "ds_read_b64_tr_b8 %9, %11 offset:6400\n\t"
+                "s_waitcnt lgkmcnt(0)"
+                : "=&v"(fa0), "=&v"(fa1), "=&v"(gb[0][0]), "=&v"(gb[0][1]), "=&v"(gb[1][0]), "=&v"(gb[1][1]), "=&v"(gb[2][0]), "=&v"(gb[2][1]),
+                  "=&v"(gb[3][0]), "=&v"(gb[3][1])
+                : "v"(a0), "v"(b0)
+                : "memory");
+            const u64 sx = 0x8080808080808080ull;
+            fa0 ^= sx;
+            fa1 ^= sx;
+            const v4i A = v4i{(int)(u32)fa0, (int)(u32)(fa0 >> 32), (int)(u32)fa1, (int)(u32)(fa1 >> 32)};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const u64 x0 = gb[e][0] ^ sx, x1 = gb[e][1] ^ sx;
+                const v4i B = v4i{(int)(u32)x0, (int)(u32)(x0 >> 32), (int)(u32)x1, (int)(u32)(x1 >> 32)};
+                acc[e] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, B, acc[e], 0, 0, 0);
+            }
+        }
+        { // plain sums: lane l adds entry l of rows F_w and G_w
+            const u32x4 flo = sh[t % 3][w][2 * lane], fhi = sh[t % 3][w][2 * lane + 1];
+            const u32x4 glo = sh[t % 3][4 + w][2 * lane], ghi = sh[t % 3][4 + w][2 * lane + 1];
+            u32 c = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sf[k] = __builtin_addc(sf[k], flo[k], c, &c);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sf[4 + k] = __builtin_addc(sf[4 + k], fhi[k], c, &c);
+            sf[8] += c;
+            c = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sg[k] = __builtin_addc(sg[k], glo[k], c, &c);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sg[4 + k] = __builtin_addc(sg[4 + k], ghi[k], c, &c);
+            sg[8] += c;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the tile is consumed before its slot is restaged
+        }
+    }
+    // ---- epilogue: once per wave
+    __syncthreads(); // every wave is done with the ring: it becomes scratch (4 KiB per wave)
+    int* mat = reinterpret_cast<int*>(&sh[0][0][0]) + w * 1024;
+    const fq r2 = {FQ_R2_LIMBS};
+    fq mine[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        // C layout of the 32x32 result: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) mat[((k & 3) + 8 * (k >> 2) + 4 * (lane >> 5)) * 32 + (lane & 31)] = acc[e][k];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        long long d = 0; // D[k], k = lane: the anti-diagonal i + i' = k (lane 63: empty)
+        const int klo = lane > 31 ? lane - 31 : 0, khi = lane < 31 ? lane : 31;
+        for (int i = klo; i <= khi && lane < 63; ++i) d += mat[i * 32 + (lane - i)];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // D[k] * 256^k * 2^-256 mod p: |D| < 2^37 as a field element times the constant, sign restored afterwards
+        const bool neg = d < 0;
+        const unsigned long long ad = (unsigned long long)(neg ? -d : d);
+        fq x = fq_zero();
+        x.v[0] = (u32)ad;
+        x.v[1] = (u32)(ad >> 32);
+        fq wk;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) wk.v[k] = kPow256ModP[lane < 63 ? lane : 0][k];
+        fq prod = fq_mul(x, wk);
+        if (neg) prod = fq_sub(fq_zero(), prod);
+        mine[e] = fq_wave_sum(prod);
+    }
+    // plain sums -> field elements: low 256 bits reduced, the overflow word times 2^256 mod p (fq_mul by R^2 = times R)
+    fq lo, hi;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) lo.v[k] = sf[k];
+    hi = fq_zero();
+    hi.v[0] = sf[8];
+    const fq asum = fq_wave_sum(fq_add(fq_reduce_256(lo), fq_mul(hi, r2)));
+#pragma unroll
+    for (int k = 0; k < 8; ++k) lo.v[k] = sg[k];
+    hi.v[0] = sg[8];
+    const fq bsum = fq_wave_sum(fq_add(fq_reduce_256(lo), fq_mul(hi, r2)));
+    if (lane == 0) {
+        fq* out = partials + ((size_t)term * gridDim.x + blockIdx.x) * 24;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) fq_store(out + 4 * w + e, mine[e]);
+        fq_store(out + 16 + w, asum);
+        fq_store(out + 20 + w, bsum);
+    }
+}
+
+// second stage of k_sum16_mfma: one block per (term, value): out48[term * 24 + v] = sum over the workgroups (fixed order)
+__global__ void __launch_bounds__(kThreads) k_reduce48(const fq* __restrict__ partials, int gx, fq* __restrict__ out48) {
+    const int term = blockIdx.x / 24, v = blockIdx.x % 24;
+    fq acc[1] = {fq_zero()};
+    for (int b = threadIdx.x; b < gx; b += kThreads) acc[0] = fq_add(acc[0], fq_load(partials + ((size_t)term * gx + b) * 24 + v));
+    block_sum_store<1>(acc, out48);
+}
+// 2 x (16 signed cross sums, 4 + 4 plain sums) -> the nine sums S[3Y + t] (through U, as k_sum9_from_u).  One block of 64 threads.
+__global__ void __launch_bounds__(64) k_sum9_from_p16(const fq* __restrict__ in48, fq qn /* the number of quarter-indices, as a plain integer */,
+                                                      fq* __restrict__ out) {
+    __shared__ fq P[2][16];
+    __shared__ fq U[9];
+    const int t = threadIdx.x;
+    if (t < 32) { // P[e][e'] = P_signed + 128 c1 (A_e + B_e') 2^-256 - 2^14 c1^2 N 2^-256
+        const int term = t >> 4, e = (t >> 2) & 3, e2 = t & 3;
+        const fq k1 = {FQ_SUM16_K1}, k2 = {FQ_SUM16_K2};
+        const fq ab = fq_add(fq_load(in48 + term * 24 + 16 + e), fq_load(in48 + term * 24 + 20 + e2));
+        P[term][4 * e + e2] = fq_add(fq_add(fq_load(in48 + term * 24 + 4 * e + e2), fq_mul(k1, ab)), fq_mul(k2, qn));
+    }
+    __syncthreads();
+    if (t < 9) { // U[a][b]: a on the top variable (bit 1 of e), b on the second (bit 0); 0, 1, 2 = '+'
+        const int a = t % 3, b = t / 3;
+        fq u = fq_zero();
+        for (int term = 0; term < 2; ++term)
+            for (int e = 0; e < 4; ++e)
+                for (int e2 = 0; e2 < 4; ++e2) {
+                    const bool in1 = (a == 2 || (e >> 1) == a) && (b == 2 || (e & 1) == b);
+                    const bool in2 = (a == 2 || (e2 >> 1) == a) && (b == 2 || (e2 & 1) == b);
+                    if (in1 && in2) u = fq_add(u, P[term][4 * e + e2]);
+                }
+        U[3 * b + a] = u;
+    }
+    __syncthreads();
+    if (t < 9) {
+        const int Y = t / 3, tt = t % 3;
+        auto V = [&](int a) -> fq { // V[a][Y]
+            if (Y < 2) return U[3 * Y + a];
+            const fq u0 = U[a], u1 = U[3 + a], up = U[6 + a];
+            const fq u1x2 = fq_dbl(u1);
+            return fq_sub(fq_add(fq_add(fq_dbl(u0), u0), fq_add(fq_dbl(u1x2), u1x2)), fq_dbl(up));
+        };
+        fq r;
+        if (tt < 2) r = V(tt);
+        else r = fq_sub(fq_dbl(fq_add(V(0), V(1))), V(2));
+        fq_store(out + t, r);
+    }
+}
+
 // U (in[3 b + a], see k_sum9_lazy) -> the nine sums S[3Y + t].  One block of 64 threads.
 __global__ void __launch_bounds__(64) k_sum9_from_u(const fq* __restrict__ in, fq* __restrict__ out) {
     const int s = threadIdx.x;
@@ -1263,7 +1467,7 @@ int launch_multifold_wide(int m, const void* src, void* dst, size_t Lout, const 
     if (gates.wide_mfma_from_log < 63 && Lout >= ((size_t)1 << std::max(gates.wide_mfma_from_log, 0))) {
         // the contraction on the matrix cores: weight tiles by a small multi-workgroup kernel, then the LDS-DMA stream
         const fq kfix = {{0xe5f7fc63u, 0xf613786fu, 0x795bc6d2u, 0xbe62fc84u, 0x799d7fdeu, 0xed6bec43u, 0x8c88f1adu, 0x164bcf99u}};
-        hipLaunchKernelGGL(k_eq_weights_mfma, dim3(1u << (m > 4 ? m - 4 : 0)), dim3(kThreads), 0, st, ch, m, (u32*)wbuf);
+        hipLaunchKernelGGL(k_eq_weights_mfma, dim3(1u << (m - 1)), dim3(kThreads), 0, st, ch, m, (u32*)wbuf); // one workgroup per b-pair's tiles
         size_t per = ((Lout >> log_ob) / 64 + 3) / 4, cap = (size_t)(256 * gates.wide_mfma_wg_per_cu) >> log_ob;
         if (per > cap) per = cap;
         if (per < 1) per = 1;
@@ -1350,9 +1554,26 @@ void launch_fold4(const void* const s[4], void* const d[4], size_t half, const u
     for (int k = 0; k < 4; ++k) { S.t[k] = (const fq*)s[k]; D.t[k] = (fq*)d[k]; }
     hipLaunchKernelGGL(k_fold4, dim3(grid_for(half)), dim3(kThreads), 0, st, S, D, half, to_fq(r));
 }
-void launch_sum9(const void* const t[4], size_t q, const uint64_t fix24[4], int lazy_from_log, void* partials, void* out, hipStream_t st) {
+void launch_sum9(const void* const t[4], size_t q, const uint64_t fix24[4], int lazy_from_log, void* partials, void* out, hipStream_t st,
+                 const DmaGates& gates) {
     Tab4 T;
     for (int k = 0; k < 4; ++k) T.t[k] = (const fq*)t[k];
+    if (gates.sum9_mfma_from_log < 63 && q % 64 == 0 && q >= ((size_t)1 << std::max(gates.sum9_mfma_from_log, 0)) &&
+        q <= ((size_t)kMaxBlocks9 << 16)) { // the matrix cores
+        size_t gx = q / 64;
+        if (gx > (size_t)kMaxBlocks9) gx = kMaxBlocks9;
+        // i32 accumulators hold 2^17 quarter-indices; kMaxBlocks9 workgroups cover q <= 2^26 with 2^16 each (beyond: launch_sum9's caller
+        // would need a larger partials buffer -- the reduced-accumulation kernel takes over)
+        fq* red = (fq*)partials + 2 * gx * 24; // 48 reduced values behind the partials (kSum9PartialElems)
+        fq qn{};
+        qn.v[0] = (u32)q;
+        qn.v[1] = (u32)((u64)q >> 32);
+        g_forms |= kFormSum9Mfma;
+        hipLaunchKernelGGL(k_sum16_mfma, dim3((unsigned)gx, 2), dim3(kThreads), 0, st, T, q, (fq*)partials);
+        hipLaunchKernelGGL(k_reduce48, dim3(48), dim3(kThreads), 0, st, (const fq*)partials, (int)gx, red);
+        hipLaunchKernelGGL(k_sum9_from_p16, dim3(1), dim3(64), 0, st, (const fq*)red, qn, (fq*)out);
+        return;
+    }
     if (lazy_from_log >= 0 && lazy_from_log < 63 && q >= 64 && q >= ((size_t)1 << lazy_from_log)) { // large: unreduced accumulation, one wave per Y
         size_t gx = (q + 63) / 64;
         if (gx > (size_t)kMaxBlocks9) gx = kMaxBlocks9;

@@ -52,7 +52,7 @@ static int ctx_create(int device_id, bool own_stream, hipStream_t stream, zk_ctx
     void* static_scratch = nullptr; // set-up of the no-allocation entry point's scratch for this device, with it current
     if (fail(hipSetDevice(device_id), "hipSetDevice") || fail(zkk::static_scratch_ptr(&static_scratch), "hipGetSymbolAddress(scratch)") ||
         (own_stream && fail(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking), "hipStreamCreate")) ||
-        fail(hipMalloc(&c->partials, (size_t)(std::max(zkk::kMaxBlocks * 3, zkk::kMaxBlocks9 * 18) + 16) * kElem), "hipMalloc partials") ||
+        fail(hipMalloc(&c->partials, std::max((size_t)zkk::kMaxBlocks * 3 + 16, zkk::kSum9PartialElems) * kElem), "hipMalloc partials") ||
         fail(hipMalloc(&c->sums_dev, kSums * kElem), "hipMalloc sums") ||
         fail(hipMalloc(&c->wide_w, zkk::kWideWeightWords * sizeof(uint32_t)), "hipMalloc wide weights") ||
         fail(hipHostMalloc((void**)&c->sums_host, kHostStage * kElem, hipHostMallocMapped), "hipHostMalloc sums") ||
@@ -844,7 +844,7 @@ static int prove_sum2x2_pairs(zk_ctx* c, const void* const tables[4], size_t len
     int pass = 0;
     if (curlen > kHostTail) {
         ProfScope ps(c, ZK_K_SUM9, (uint64_t)len * 32 * 4);
-        zkk::launch_sum9(cur, curlen / 4, c->two24, c->deg2_lazy_from_log, c->partials, c->sums_host_dev, c->stream); // nine sums straight into pinned host memory
+        zkk::launch_sum9(cur, curlen / 4, c->two24, c->deg2_lazy_from_log, c->partials, c->sums_host_dev, c->stream, c->gates); // nine sums straight into pinned host memory
     }
     while (curlen > kHostTail) {
         HIPCHK(c, hipGetLastError());
@@ -868,7 +868,7 @@ static int prove_sum2x2_pairs(zk_ctx* c, const void* const tables[4], size_t len
         }
         if (outlen > kHostTail) {
             ProfScope ps(c, ZK_K_SUM9, (uint64_t)outlen * 32 * 4);
-            zkk::launch_sum9(dst, outlen / 4, c->two24, c->deg2_lazy_from_log, c->partials, c->sums_host_dev, c->stream);
+            zkk::launch_sum9(dst, outlen / 4, c->two24, c->deg2_lazy_from_log, c->partials, c->sums_host_dev, c->stream, c->gates);
         }
         for (int t = 0; t < 4; ++t) cur[t] = dst[t];
         curlen = outlen;
@@ -1011,7 +1011,7 @@ int zk_shard4_sum9(zk_shard4* s, void* sums_dev_out) {
     if (rc) return rc;
     {
         ProfScope ps(c, ZK_K_SUM9, (uint64_t)s->len * 32 * 4);
-        zkk::launch_sum9(s->cur, s->len / 4, c->two24, c->deg2_lazy_from_log, c->partials, sums_dev_out, c->stream);
+        zkk::launch_sum9(s->cur, s->len / 4, c->two24, c->deg2_lazy_from_log, c->partials, sums_dev_out, c->stream, c->gates);
     }
     HIPCHK(c, hipGetLastError());
     return ZK_OK;
@@ -1036,7 +1036,7 @@ int zk_shard4_fold2(zk_shard4* s, const uint64_t r2[8], void* sums_dev_out) {
     }
     if (sums_dev_out && outlen >= 4) {
         ProfScope ps(c, ZK_K_SUM9, (uint64_t)outlen * 32 * 4);
-        zkk::launch_sum9(dst, outlen / 4, c->two24, c->deg2_lazy_from_log, c->partials, sums_dev_out, c->stream);
+        zkk::launch_sum9(dst, outlen / 4, c->two24, c->deg2_lazy_from_log, c->partials, sums_dev_out, c->stream, c->gates);
     }
     HIPCHK(c, hipGetLastError());
     for (int t = 0; t < 4; ++t) s->cur[t] = dst[t];
@@ -1134,6 +1134,11 @@ int zk_ctx_set_tail_fold(zk_ctx* c, int max_log_table, int out_below_log) {
 int zk_ctx_set_deg2_lazy_sums(zk_ctx* c, int from_log) {
     if (!c || from_log > 62) return ZK_E_ARG;
     c->deg2_lazy_from_log = from_log;
+    return ZK_OK;
+}
+int zk_ctx_set_deg2_mfma_sums(zk_ctx* c, int from_log) {
+    if (!c || from_log < 0 || from_log > 64) return ZK_E_ARG;
+    c->gates.sum9_mfma_from_log = from_log;
     return ZK_OK;
 }
 int zk_ctx_set_deg2_rounds_per_pass(zk_ctx* c, int rounds) {
