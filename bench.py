@@ -60,6 +60,7 @@ def parse(argv=None):
     ap.add_argument("--wide-mfma", type=int, default=None, help="wide fold passes with >= 2^k outputs contract on the matrix cores (64 = never; default: library default)")
     ap.add_argument("--wide-mfma-wg", type=int, default=1, help="workgroups per CU of the matrix-core wide fold")
     ap.add_argument("--wide-mfma-depth", type=int, default=2, help="steps in flight per wave of the matrix-core wide fold (2..4)")
+    ap.add_argument("--deg2-mfma-from", type=int, default=None, help="degree-2 prover: nine sums on the matrix cores from 2^k quarter-entries (64 = never)")
     ap.add_argument("--weak", action="store_true", help="multi-GPU: 2^log_n entries PER GPU instead of in total")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend of the ranks' rendezvous (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--shared-device", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
@@ -258,6 +259,8 @@ def apply_knobs(args, ctx):
         ctx.set_deg2_rounds_per_pass(args.deg2_rounds)
     if args.deg2_lazy_from is not None:
         ctx.set_deg2_lazy_sums(args.deg2_lazy_from)
+    if args.deg2_mfma_from is not None:
+        ctx.set_deg2_mfma_sums(args.deg2_mfma_from)
 
 
 def read_kernels(ctx, names=KERNEL_NAMES):

@@ -155,19 +155,21 @@ def test_sumcheck_2pow30_largest_benchmark_size():
 
 
 def test_sum2x2_2pow24_both_nine_sum_kernels_agree():
-    """The unreduced-accumulation sweep (k_sum9_lazy, LDS-DMA ring) and the per-product-reduction sweep give the same
-    proof bytes at a size where the former is the default."""
+    """The unreduced-accumulation sweep (k_sum9_lazy, LDS-DMA ring), the per-product-reduction sweep and the matrix-core
+    sweep (k_sum16_mfma, the default from 2^22 quarter-entries) give the same proof bytes at full size."""
     proofs = []
-    for lazy_from in (20, -1):
+    for lazy_from, mfma_from in ((20, 64), (-1, 64), (20, 22)):
         ctx = zk_amd.Context(0)
         ctx.set_deg2_lazy_sums(lazy_from)
+        ctx.set_deg2_mfma_sums(mfma_from)
         tabs = [MLE.generate(SEED + 80 + k, 1 << 24, ctx=ctx) for k in range(4)]
         f = zk_amd.SumPolynomial([zk_amd.ProductPolynomial(tabs[:2]), zk_amd.ProductPolynomial(tabs[2:])])
         proof, pts = zk_amd.SumcheckProver.generate_proof_for_partial_verify(O.fq1(0), f, zk_amd.Transcript())
         proofs.append((proof.round_polys.copy(), pts.copy()))
         del tabs, f
         ctx.close()
-    assert np.array_equal(proofs[0][0], proofs[1][0]) and np.array_equal(proofs[0][1], proofs[1][1])
+    for other in proofs[1:]:
+        assert np.array_equal(proofs[0][0], other[0]) and np.array_equal(proofs[0][1], other[1])
 
 
 def test_constant_tables_of_p_minus_1_worst_case_limbs():
@@ -192,12 +194,14 @@ def test_constant_tables_of_p_minus_1_worst_case_limbs():
     del poly
     proofs = []
     m = 1 << 23
-    for lazy_from in (18, -1):
+    for lazy_from, mfma_from in ((18, 64), (-1, 64), (18, 0)):  # the last: every sweep on the matrix cores
         ctx.set_deg2_lazy_sums(lazy_from)
+        ctx.set_deg2_mfma_sums(mfma_from)
         tabs = [MLE(np.ascontiguousarray(np.broadcast_to(pm1, (m, 4))), ctx=ctx) for _ in range(4)]
         f = zk_amd.SumPolynomial([zk_amd.ProductPolynomial(tabs[:2]), zk_amd.ProductPolynomial(tabs[2:])])
         proof, pts = zk_amd.SumcheckProver.generate_proof_for_partial_verify(O.fq1(0), f, zk_amd.Transcript())
         proofs.append((proof.round_polys.copy(), pts.copy()))
         del tabs, f
-    assert np.array_equal(proofs[0][0], proofs[1][0]) and np.array_equal(proofs[0][1], proofs[1][1])
+    for other in proofs[1:]:
+        assert np.array_equal(proofs[0][0], other[0]) and np.array_equal(proofs[0][1], other[1])
     ctx.close()

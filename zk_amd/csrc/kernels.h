@@ -43,7 +43,7 @@ struct DmaGates {
     int fold2_from_log = 22;       // degree-2 two-variable fold by LDS-DMA from 2^k outputs per table
     int wide_mfma_from_log = 15;   // wide fold on the matrix cores (k_multifold_wide_mfma) from 2^k outputs; 64 = never
     int wide_mfma_wg_per_cu = 1;   // its grid: workgroups per CU (1 and 2 measure alike; LDS admits two at depth 2)
-    int sum9_mfma_from_log = 64;   // nine sums on the matrix cores (k_sum16_mfma) from 2^k quarter-entries; 64 = never
+    int sum9_mfma_from_log = 22;   // nine sums on the matrix cores (k_sum16_mfma) from 2^k quarter-entries (measured break-even); 64 = never
     int wide_mfma_depth = 2;       // its pipeline depth K (2..4): table rows of K steps in flight per wave
 };
 // out[b] (b < 2^log_ob) = sum of the b-th contiguous block of T (L entries); partials is scratch
