@@ -61,6 +61,8 @@ def parse(argv=None):
     ap.add_argument("--wide-mfma-wg", type=int, default=1, help="workgroups per CU of the matrix-core wide fold")
     ap.add_argument("--wide-mfma-depth", type=int, default=2, help="steps in flight per wave of the matrix-core wide fold (2..4)")
     ap.add_argument("--deg2-mfma-from", type=int, default=None, help="degree-2 prover: nine sums on the matrix cores from 2^k quarter-entries (64 = never)")
+    ap.add_argument("--deg2-triple-from", type=int, default=None, help="degree-2 prover: three rounds per pass on tables of >= 2^k entries (64 = never)")
+    ap.add_argument("--deg2-triple-ring", type=int, default=3, help="LDS tiles of the three-round sweep (3 or 4)")
     ap.add_argument("--weak", action="store_true", help="multi-GPU: 2^log_n entries PER GPU instead of in total")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend of the ranks' rendezvous (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--shared-device", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
@@ -261,6 +263,8 @@ def apply_knobs(args, ctx):
         ctx.set_deg2_lazy_sums(args.deg2_lazy_from)
     if args.deg2_mfma_from is not None:
         ctx.set_deg2_mfma_sums(args.deg2_mfma_from)
+    if args.deg2_triple_from is not None:
+        ctx.set_deg2_triple(args.deg2_triple_from, args.deg2_triple_ring)
 
 
 def read_kernels(ctx, names=KERNEL_NAMES):

@@ -361,12 +361,18 @@ int zk_ctx_set_wide_mfma(zk_ctx *ctx, int from_log, int workgroups_per_cu, int d
  * assert that the form it forced is the one that ran. */
 enum { ZK_FORM_SUMS_DMA = 1 << 0, ZK_FORM_SUMS_REG = 1 << 1, ZK_FORM_WIDE_DMA = 1 << 2, ZK_FORM_WIDE_DMA_STREAM = 1 << 3,
        ZK_FORM_WIDE_REG = 1 << 4, ZK_FORM_WIDE_LDS = 1 << 5, ZK_FORM_COOP = 1 << 6, ZK_FORM_FOLD2_DMA = 1 << 7,
-       ZK_FORM_FOLD2_REG = 1 << 8, ZK_FORM_SUM9_LAZY = 1 << 9, ZK_FORM_SUM9 = 1 << 10, ZK_FORM_FOLD2_SUM9 = 1 << 11, ZK_FORM_WIDE_MFMA = 1 << 12, ZK_FORM_SUM9_MFMA = 1 << 13 };
+       ZK_FORM_FOLD2_REG = 1 << 8, ZK_FORM_SUM9_LAZY = 1 << 9, ZK_FORM_SUM9 = 1 << 10, ZK_FORM_FOLD2_SUM9 = 1 << 11, ZK_FORM_WIDE_MFMA = 1 << 12, ZK_FORM_SUM9_MFMA = 1 << 13,
+       ZK_FORM_CROSS64 = 1 << 14, ZK_FORM_FOLD3_DMA = 1 << 15 };
 unsigned zk_ctx_forms_used(zk_ctx *ctx, int reset);
 /* Nine-sum sweeps over tables of at least 2^from_log quarter-entries (64 = never) run on the matrix cores: the sixteen cross sums
  * of a term's entries as 32 x 32 byte-product matrices (v_mfma_i32_32x32x32_i8 with the contraction over the quarter-index,
  * operands through ds_read_b64_tr_b8), mapped to the nine sums exactly.  Proof bytes do not depend on it. */
 int zk_ctx_set_deg2_mfma_sums(zk_ctx *ctx, int from_log);
+/* Degree-2 prover (SumPolynomial branch, sumcheck/src/prover.rs:89-107, :131-139): passes over four tables of at least 2^from_log
+ * entries (64 = never; tables of whole 64-entry eighths only) serve THREE rounds each: one sweep forms the 8 x 8 cross sums
+ * sum_j F_e[j] G_e'[j] of both terms on the matrix cores, the host runs three rounds on them, one fold binds the three variables.
+ * ring = 3 or 4 LDS tiles in the sweep.  An execution schedule: proof bytes do not depend on it. */
+int zk_ctx_set_deg2_triple(zk_ctx *ctx, int from_log, int ring);
 enum { ZK_K_BLOCK_SUMS = 0, ZK_K_MULTIFOLD = 1, ZK_K_FOLD = 2, ZK_K_EVAL3 = 3, ZK_K_FOLD4_EVAL3 = 4, ZK_K_SUM9 = 5, ZK_K_FOLD2X4_SUM9 = 6, ZK_K_MULTIFOLD_WIDE = 7, ZK_K_MULTIFOLD_TAIL = 8,
        ZK_K_COUNT = 10 };
 /* per-kernel HIP-event timing of the launches made by the provers on this context */

@@ -578,6 +578,59 @@ def test_sum2x2_mfma_nine_sums_vs_oracle(log_n):
     assert np.array_equal(pts, och) and tr.peek_digest() == otr.peek_digest()
 
 
+# ---- three rounds per pass: 8 x 8 cross sums per term (k_cross64_mfma) + the m = 3 fold -------------------------------------------
+@pytest.mark.parametrize("ring", [3, 4])
+@pytest.mark.parametrize("log_n", [9, 10, 11, 12, 13, 15, 17])
+def test_sum2x2_three_rounds_per_pass_vs_oracle(log_n, ring):
+    """Every pass whose tables are whole 64-entry eighths serves three rounds (cross sums on the matrix cores, host rounds from
+    them, one three-variable fold); the rest of the prove runs the two-round and host forms.  Same proof bytes as the oracle."""
+    c = zk_amd.Context(0)
+    c.set_deg2_triple(0, ring)
+    n = 1 << log_n
+    tabs = [O.gen_table(SEED + 260 + k, 0, n) for k in range(4)]
+    m = [MLE(t, ctx=c) for t in tabs]
+    f = zk_amd.SumPolynomial([zk_amd.ProductPolynomial(m[:2]), zk_amd.ProductPolynomial(m[2:])])
+    tr, otr = zk_amd.Transcript(), O.OTranscript()
+    c.forms_used()
+    proof, pts = zk_amd.SumcheckProver.generate_proof_for_partial_verify(O.fq1(5), f, tr)
+    forms = c.forms_used()
+    assert "cross64" in forms and "fold3_dma" in forms, forms
+    ocoeffs, och = O.sumcheck_prove_sum([[tabs[0], tabs[1]], [tabs[2], tabs[3]]], O.fq1(5), otr)
+    assert np.array_equal(proof.round_polys, ocoeffs), log_n
+    assert np.array_equal(pts, och) and tr.peek_digest() == otr.peek_digest()
+    for t, src in zip(m, tabs):
+        assert np.array_equal(t.get_evaluation_points(), src)      # the factor tables are left unmodified
+
+
+@pytest.mark.parametrize("fill", ["p-1", "zero", "byteff", "mixed"])
+def test_sum2x2_three_rounds_per_pass_extreme_bytes(fill):
+    c = zk_amd.Context(0)
+    c.set_deg2_triple(0, 3)
+    n = 1 << 12
+
+    def const_table(raw):
+        assert raw < P
+        return np.tile(np.array([(raw >> (64 * k)) & (2**64 - 1) for k in range(4)], dtype=np.uint64), (n, 1))
+
+    if fill == "p-1":
+        tabs = [O.ints_to_mont([P - 1] * n)] * 4
+    elif fill == "zero":
+        tabs = [np.zeros((n, 4), dtype=np.uint64)] * 4
+    elif fill == "byteff":
+        tabs = [const_table(int.from_bytes(bytes([0xff] * 31 + [0x2f]), "little"))] * 4
+    else:
+        tabs = [const_table(int.from_bytes(bytes([0xff] * 31 + [0x2f]), "little")), np.zeros((n, 4), dtype=np.uint64),
+                const_table(int.from_bytes(bytes([0x7f, 0x80] * 15 + [0x00, 0x30]), "little")), O.gen_table(SEED, 0, n)]
+    m = [MLE(t, ctx=c) for t in tabs]
+    f = zk_amd.SumPolynomial([zk_amd.ProductPolynomial(m[:2]), zk_amd.ProductPolynomial(m[2:])])
+    tr, otr = zk_amd.Transcript(), O.OTranscript()
+    c.forms_used()
+    proof, pts = zk_amd.SumcheckProver.generate_proof_for_partial_verify(O.fq1(1), f, tr)
+    assert "cross64" in c.forms_used()
+    ocoeffs, och = O.sumcheck_prove_sum([[tabs[0], tabs[1]], [tabs[2], tabs[3]]], O.fq1(1), otr)
+    assert np.array_equal(proof.round_polys, ocoeffs) and np.array_equal(pts, och)
+
+
 @pytest.mark.parametrize("fill", ["p-1", "zero", "byte80", "byteff", "mixed"])
 def test_sum2x2_mfma_nine_sums_extreme_bytes(fill):
     c = zk_amd.Context(0)

@@ -9,7 +9,7 @@ KERNELS = {"block_sums": 0, "multifold": 1, "fold": 2, "eval3": 3, "fold4_eval3"
 
 
 FORMS = ["sums_dma", "sums_reg", "wide_dma", "wide_dma_stream", "wide_reg", "wide_lds", "coop", "fold2_dma", "fold2_reg", "sum9_lazy", "sum9",
-         "fold2_sum9", "wide_mfma", "sum9_mfma"]
+         "fold2_sum9", "wide_mfma", "sum9_mfma", "cross64", "fold3_dma"]
 
 
 class Context:
@@ -72,6 +72,11 @@ class Context:
     def set_deg2_mfma_sums(self, from_log: int = 16):
         """Degree-2 prover: nine-sum sweeps over >= 2^from_log quarter-entries run on the matrix cores (64 = never)."""
         check(lib().zk_ctx_set_deg2_mfma_sums(self.h, from_log))
+
+    def set_deg2_triple(self, from_log: int = 64, ring: int = 3):
+        """Degree-2 prover: passes over tables of >= 2^from_log entries serve three rounds each (8 x 8 cross sums per term on the
+        matrix cores + one three-variable fold); 64 = never.  ring = LDS tiles of the sweep (3 or 4)."""
+        check(lib().zk_ctx_set_deg2_triple(self.h, from_log, ring))
 
     def set_dma_gates(self, sums_from_log: int = 27, wide_stream_from_log: int = 22, fold2_from_log: int = 22):
         """Size thresholds (log2 entries, 64 = never) of the LDS-DMA forms of the big passes.  Proof bytes do not depend on it."""

@@ -34,6 +34,8 @@ enum Form : unsigned {
     kFormFold2Sum9 = 1u << 11,    // k_fold2_sum9 (fold fused with the next nine sums)
     kFormWideMfma = 1u << 12,     // k_multifold_wide_mfma (the wide pass on the matrix cores)
     kFormSum9Mfma = 1u << 13,     // k_sum16_mfma (the nine sums on the matrix cores)
+    kFormCross64 = 1u << 14,      // k_cross64_mfma (three rounds per pass: 8 x 8 cross sums per term on the matrix cores)
+    kFormFold3Dma = 1u << 15,     // m = 3 LDS-DMA fold of the degree-2 branch (three rounds per pass)
 };
 extern thread_local unsigned g_forms;
 // Size thresholds of the LDS-DMA forms (log2 of entries; defaults = the measured break-even points)
@@ -45,6 +47,8 @@ struct DmaGates {
     int wide_mfma_wg_per_cu = 1;   // its grid: workgroups per CU (1 and 2 measure alike; LDS admits two at depth 2)
     int sum9_mfma_from_log = 22;   // nine sums on the matrix cores (k_sum16_mfma) from 2^k quarter-entries (measured break-even); 64 = never
     int wide_mfma_depth = 2;       // its pipeline depth K (2..4): table rows of K steps in flight per wave
+    int deg2_triple_from_log = 21; // degree-2 prover: three rounds per pass (k_cross64_mfma + m = 3 fold) on tables of >= 2^k entries; 64 = never
+    int deg2_triple_ring = 4;      // its LDS ring: 3 or 4 tiles of 32 KiB
 };
 // out[b] (b < 2^log_ob) = sum of the b-th contiguous block of T (L entries); partials is scratch
 int launch_block_sums(const void* T, size_t L, int log_ob, void* partials, void* out, hipStream_t st, const DmaGates& gates = DmaGates());
@@ -76,7 +80,7 @@ void launch_fold4(const void* const s[4], void* const d[4], size_t half, const u
 // degree-2 branch, two rounds per pass (kernels.hip): out[3Y + t] (9 elements) = the nine sums of four tables of 4q
 // entries; partials must hold kSum9PartialElems elements
 static constexpr int kMaxBlocks9 = 1024;
-static constexpr size_t kSum9PartialElems = (size_t)48 * kMaxBlocks9 + 64; // elements `partials` must hold for launch_sum9
+static constexpr size_t kSum9PartialElems = (size_t)160 * kMaxBlocks9 + 256; // elements `partials` must hold for launch_sum9 / launch_cross64
 // fix24 = 2^24 (Montgomery); tables of at least 2^lazy_from_log quarter-entries take the unreduced-accumulation kernel
 // (lazy_from_log < 0: never)
 void launch_sum9(const void* const t[4], size_t q, const uint64_t fix24[4], int lazy_from_log, void* partials, void* out, hipStream_t st,
@@ -86,6 +90,14 @@ void launch_sum9(const void* const t[4], size_t q, const uint64_t fix24[4], int 
 // wbuf (device, >= 40 u32) and partials (>= 1024 elements) are scratch for the large-table form; either may be null (then never used)
 void launch_fold2_tables(const void* const s[4], void* const d[4], size_t outlen, const uint32_t* w28, void* wbuf, void* partials, hipStream_t st,
                          const DmaGates& gates = DmaGates());
+// degree-2 branch, THREE rounds per pass: out[term * 64 + 8 e + e'] (128 elements) = sum_j F_e[j] G_e'[j] of term (F, G) = (t[2 term],
+// t[2 term + 1]), tables of 8 q entries, entry e of quarter-index j at e q + j; needs cross64_fits(q); ring = 3 or 4 LDS tiles
+bool cross64_fits(size_t q);
+void launch_cross64(const void* const t[4], size_t q, int ring, void* partials, void* out, hipStream_t st);
+// bind the three top variables of four tables of 8 * outlen entries at r3[0..3) (4 limbs each) into d[] (outlen entries each, a
+// multiple of 64); wbuf (>= 80 u32) and partials (>= 1024 elements) are scratch
+void launch_fold3_tables(const void* const s[4], void* const d[4], size_t outlen, const uint64_t* r3, const uint64_t two24[4], void* wbuf,
+                         void* partials, hipStream_t st, const DmaGates& gates = DmaGates());
 // out[k*n + i] = t[k][i], k < 4, i < n
 void launch_gather4(const void* const t[4], size_t n, void* out, hipStream_t st);
 // out[(t * L + j) * world + q] = in[(q * ntab + t) * L + j]: the ranks' gathered local tables (rank-major) -> the remaining

@@ -1218,6 +1218,178 @@ __global__ void __launch_bounds__(64) k_sum9_from_p16(const fq* __restrict__ in4
     }
 }
 
+// ---- THREE rounds per pass: the 8 x 8 cross sums of a term on the matrix cores -------------------------------------------------
+// With the three top variables as index e = 4 b1 + 2 b2 + b3 (tables of 8 q entries, entry e of quarter-index j at e q + j) the
+// 64 cross sums  P[e][e'] = sum_j F_e[j] G_e'[j]  per term determine THREE rounds on the host (zkmi.cpp, host_rounds_from_cross:
+// round i needs only sum_{e,e'} eq(x,e) eq(x,e') P[e][e'] at x = (r_0..r_{i-1}, X, y) -- exact arithmetic, the same field elements
+// as the reference's per-round sums), and one fold with the eight weights eq((r0,r1,r2), .) binds all three variables: per prove
+// the tables are read 8/7 + (9/8)(8/7) = 2.43 times instead of 3.0 (two rounds per pass).  Same scheme as k_sum16_mfma -- bytes
+// as signed i8, v_mfma_i32_32x32x32_i8 with the contraction over j, operands by ds_read_b64_tr_b8 -- with eight waves per workgroup:
+// wave w keeps C[e = w][e' = 0..7] (128 accumulator registers) and the plain sums of rows F_w and G_w; a tile is 16 rows x 2 KiB,
+// staged by LDS-DMA through a ring of R tiles (R - 1 in flight; 32 R KiB of LDS: one workgroup per CU).
+// partials: [(term * gridDim.x + bx) * 80 + ...]: 64 values P_signed[e][e'] * 2^-256 (index 8 e + e'), then A_e (8), then B_e' (8).
+template <int R>
+__global__ void __launch_bounds__(512) k_cross64_mfma(Tab4 T, size_t q, fq* __restrict__ partials) {
+    constexpr int NE = 8;
+    __shared__ u32x4 sh[R][2 * NE][128];
+    const int term = blockIdx.y, lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const fq* __restrict__ F = T.t[2 * term];
+    const fq* __restrict__ G = T.t[2 * term + 1];
+    const size_t stride = (size_t)gridDim.x * 64, base0 = (size_t)blockIdx.x * 64;
+    const int nt = base0 < q ? (int)((q - base0 + stride - 1) / stride) : 0;
+    auto stage = [&](int t) { // wave w brings rows 2w, 2w + 1: four DMA instructions
+#pragma unroll
+        for (int r2 = 0; r2 < 2; ++r2) {
+            const int r = 2 * w + r2;
+            const fq* src = ((r & NE) ? G : F) + (size_t)(r & (NE - 1)) * q + base0 + (size_t)t * stride;
+            const u32x4* p = reinterpret_cast<const u32x4*>(src) + lane;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
+                                             (__attribute__((address_space(3))) void*)&sh[t % R][r][0], 16, 0, 2);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p + 64),
+                                             (__attribute__((address_space(3))) void*)&sh[t % R][r][64], 16, 0, 2);
+        }
+    };
+    v16i acc[NE];
+#pragma unroll
+    for (int e = 0; e < NE; ++e)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc[e][k] = 0;
+    u32 sf[9], sg[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) sf[k] = sg[k] = 0;
+    const int gg = lane >> 4, qq = (lane >> 1) & 7, pp = lane & 1; // transposed-read address inside a row: see k_sum16_mfma
+    const u32 tr_off = (u32)((16 * (gg >> 1) + qq) * 32 + 16 * (gg & 1) + 8 * pp);
+#pragma unroll
+    for (int t = 0; t < R - 1; ++t)
+        if (t < nt) stage(t);
+    for (int t = 0; t < nt; ++t) {
+        if (t + R - 2 < nt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (R - 2)) : "memory"); // tiles t+1 .. t+R-2 stay in flight
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (t + R - 1 < nt) stage(t + R - 1); // into the slot every wave finished reading before this barrier
+        const u32 tile = (u32)(uintptr_t)&sh[t % R][0][0];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) { // 32 quarter-indices per step
+            const u32 a0 = tile + (u32)w * 2048u + (u32)ks * 1024u + tr_off;  // row F_w
+            const u32 b0 = tile + (u32)NE * 2048u + (u32)ks * 1024u + tr_off; // rows G_0 .. G_7
+            u64 fa0, fa1, gb[NE][2];
+            asm volatile(
+                "ds_read_b64_tr_b8 %0, %18\n\t"
+                "ds_read_b64_tr_b8 %1, %18 offset:256\n\t"
+                "ds_read_b64_tr_b8 %2, %19\n\t"
+                "ds_read_b64_tr_b8 %3, %19 offset:256\n\t"
+                "ds_read_b64_tr_b8 %4, %19 offset:2048\n\t"
+                "ds_read_b64_tr_b8 %5, %19 offset:2304\n\t"
+                "ds_read_b64_tr_b8 %6, %19 offset:4096\n\t"
+                "ds_read_b64_tr_b8 %7, %19 offset:4352\n\t"
+                "ds_read_b64_tr_b8 %8, %19 offset:6144\n\t"
+                "ds_read_b64_tr_b8 %9, %19 offset:6400\n\t"
+                "ds_read_b64_tr_b8 %10, %19 offset:8192\n\t"
+                "ds_read_b64_tr_b8 %11, %19 offset:8448\n\t"
+                "ds_read_b64_tr_b8 %12, %19 offset:10240\n\t"
+                "ds_read_b64_tr_b8 %13, %19 offset:10496\n\t"
+                "ds_read_b64_tr_b8 %14, %19 offset:12288\n\t"
+                "ds_read_b64_tr_b8 %15, %19 offset:12544\n\t"
+                "ds_read_b64_tr_b8 %16, %19 offset:14336\n\t"
+                "ds_read_b64_tr_b8 %17, %19 offset:14592\n\t"
+                "s_waitcnt lgkmcnt(0)"
+                : "=&v"(fa0), "=&v"(fa1), "=&v"(gb[0][0]), "=&v"(gb[0][1]), "=&v"(gb[1][0]), "=&v"(gb[1][1]), "=&v"(gb[2][0]), "=&v"(gb[2][1]),
+                  "=&v"(gb[3][0]), "=&v"(gb[3][1]), "=&v"(gb[4][0]), "=&v"(gb[4][1]), "=&v"(gb[5][0]), "=&v"(gb[5][1]), "=&v"(gb[6][0]),
+                  "=&v"(gb[6][1]), "=&v"(gb[7][0]), "=&v"(gb[7][1])
+                : "v"(a0), "v"(b0)
+                : "memory");
+            const u64 sx = 0x8080808080808080ull;
+            fa0 ^= sx;
+            fa1 ^= sx;
+            const v4i A = v4i{(int)(u32)fa0, (int)(u32)(fa0 >> 32), (int)(u32)fa1, (int)(u32)(fa1 >> 32)};
+#pragma unroll
+            for (int e = 0; e < NE; ++e) {
+                const u64 x0 = gb[e][0] ^ sx, x1 = gb[e][1] ^ sx;
+                const v4i B = v4i{(int)(u32)x0, (int)(u32)(x0 >> 32), (int)(u32)x1, (int)(u32)(x1 >> 32)};
+                acc[e] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, B, acc[e], 0, 0, 0);
+            }
+        }
+        { // plain sums: lane l adds entry l of rows F_w and G_w
+            const u32x4 flo = sh[t % R][w][2 * lane], fhi = sh[t % R][w][2 * lane + 1];
+            const u32x4 glo = sh[t % R][NE + w][2 * lane], ghi = sh[t % R][NE + w][2 * lane + 1];
+            u32 c = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sf[k] = __builtin_addc(sf[k], flo[k], c, &c);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sf[4 + k] = __builtin_addc(sf[4 + k], fhi[k], c, &c);
+            sf[8] += c;
+            c = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sg[k] = __builtin_addc(sg[k], glo[k], c, &c);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sg[4 + k] = __builtin_addc(sg[4 + k], ghi[k], c, &c);
+            sg[8] += c;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the tile is consumed before its slot is restaged
+        }
+    }
+    // ---- epilogue: once per wave (as k_sum16_mfma)
+    __syncthreads(); // every wave is done with the ring: it becomes scratch (4 KiB per wave)
+    int* mat = reinterpret_cast<int*>(&sh[0][0][0]) + w * 1024;
+    const fq r2 = {FQ_R2_LIMBS};
+    fq* out = partials + ((size_t)term * gridDim.x + blockIdx.x) * (NE * NE + 2 * NE);
+    fq wk;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) wk.v[k] = kPow256ModP[lane < 63 ? lane : 0][k];
+    for (int e = 0; e < NE; ++e) { // rolled: the body is large and runs once
+        v16i a = acc[0];
+#pragma unroll
+        for (int e2 = 1; e2 < NE; ++e2)
+            if (e == e2) a = acc[e2];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) mat[((k & 3) + 8 * (k >> 2) + 4 * (lane >> 5)) * 32 + (lane & 31)] = a[k];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        long long d = 0; // D[k], k = lane: the anti-diagonal i + i' = k (lane 63: empty)
+        const int klo = lane > 31 ? lane - 31 : 0, khi = lane < 31 ? lane : 31;
+        for (int i = klo; i <= khi && lane < 63; ++i) d += mat[i * 32 + (lane - i)];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const bool neg = d < 0;
+        const unsigned long long ad = (unsigned long long)(neg ? -d : d);
+        fq x = fq_zero();
+        x.v[0] = (u32)ad;
+        x.v[1] = (u32)(ad >> 32);
+        fq prod = fq_mul(x, wk);
+        if (neg) prod = fq_sub(fq_zero(), prod);
+        const fq mine = fq_wave_sum(prod);
+        if (lane == 0) fq_store(out + NE * w + e, mine);
+    }
+    fq lo, hi;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) lo.v[k] = sf[k];
+    hi = fq_zero();
+    hi.v[0] = sf[8];
+    const fq asum = fq_wave_sum(fq_add(fq_reduce_256(lo), fq_mul(hi, r2)));
+#pragma unroll
+    for (int k = 0; k < 8; ++k) lo.v[k] = sg[k];
+    hi.v[0] = sg[8];
+    const fq bsum = fq_wave_sum(fq_add(fq_reduce_256(lo), fq_mul(hi, r2)));
+    if (lane == 0) {
+        fq_store(out + NE * NE + w, asum);
+        fq_store(out + NE * NE + NE + w, bsum);
+    }
+}
+// second stage: one block per (term, value): red[term * nv + v] = sum over the workgroups (fixed order)
+__global__ void __launch_bounds__(kThreads) k_reduce_cross(const fq* __restrict__ partials, int gx, int nv, fq* __restrict__ red) {
+    const int term = blockIdx.x / nv, v = blockIdx.x % nv;
+    fq acc[1] = {fq_zero()};
+    for (int b = threadIdx.x; b < gx; b += kThreads) acc[0] = fq_add(acc[0], fq_load(partials + ((size_t)term * gx + b) * nv + v));
+    block_sum_store<1>(acc, red);
+}
+// out[term * 64 + 8 e + e'] = P[e][e'] = P_signed + 128 c1 (A_e + B_e') 2^-256 - 2^14 c1^2 N 2^-256 (see k_sum16_mfma); one block of 128
+__global__ void __launch_bounds__(128) k_cross64_fix(const fq* __restrict__ red, fq qn, fq* __restrict__ out) {
+    const int t = threadIdx.x, term = t >> 6, e = (t >> 3) & 7, e2 = t & 7;
+    const fq k1 = {FQ_SUM16_K1}, k2 = {FQ_SUM16_K2};
+    const fq* in = red + term * 80;
+    const fq ab = fq_add(fq_load(in + 64 + e), fq_load(in + 72 + e2));
+    fq_store(out + t, fq_add(fq_add(fq_load(in + 8 * e + e2), fq_mul(k1, ab)), fq_mul(k2, qn)));
+}
+
 // U (in[3 b + a], see k_sum9_lazy) -> the nine sums S[3Y + t].  One block of 64 threads.
 __global__ void __launch_bounds__(64) k_sum9_from_u(const fq* __restrict__ in, fq* __restrict__ out) {
     const int s = threadIdx.x;
@@ -1592,6 +1764,46 @@ void launch_sum9(const void* const t[4], size_t q, const uint64_t fix24[4], int 
     if (ysplit) hipLaunchKernelGGL((k_sum9<true>), dim3((unsigned)gx, 6), dim3(kThreads), 0, st, T, q, (fq*)partials);
     else hipLaunchKernelGGL((k_sum9<false>), dim3((unsigned)gx, 2), dim3(kThreads), 0, st, T, q, (fq*)partials);
     hipLaunchKernelGGL(k_reduce9, dim3(9), dim3(kThreads), 0, st, (const fq*)partials, (int)gx, ysplit ? 1 : 0, (fq*)out);
+}
+bool cross64_fits(size_t q) { return q >= 64 && q % 64 == 0 && q <= ((size_t)kMaxBlocks9 << 17); }
+void launch_cross64(const void* const t[4], size_t q, int ring, void* partials, void* out, hipStream_t st) {
+    Tab4 T;
+    for (int k = 0; k < 4; ++k) T.t[k] = (const fq*)t[k];
+    // one workgroup per CU and term half: 128 x 2 persistent workgroups; more only to keep a workgroup's share within the i32
+    // accumulators (2^17 quarter-indices)
+    size_t gx = std::min<size_t>(q / 64, 128);
+    const size_t need = (q + ((size_t)1 << 17) - 1) >> 17;
+    if (gx < need) gx = need;
+    fq* red = (fq*)partials + 2 * gx * 80; // 160 reduced values behind the partials (kSum9PartialElems)
+    fq qn{};
+    qn.v[0] = (u32)q;
+    qn.v[1] = (u32)((u64)q >> 32);
+    g_forms |= kFormCross64;
+    if (ring == 4) hipLaunchKernelGGL((k_cross64_mfma<4>), dim3((unsigned)gx, 2), dim3(512), 0, st, T, q, (fq*)partials);
+    else hipLaunchKernelGGL((k_cross64_mfma<3>), dim3((unsigned)gx, 2), dim3(512), 0, st, T, q, (fq*)partials);
+    hipLaunchKernelGGL(k_reduce_cross, dim3(160), dim3(kThreads), 0, st, (const fq*)partials, (int)gx, 80, red);
+    hipLaunchKernelGGL(k_cross64_fix, dim3(1), dim3(128), 0, st, (const fq*)red, qn, (fq*)out);
+}
+// bind the THREE top variables of four tables of 8 * outlen entries (outlen a multiple of 64): eq weights on the device, then one
+// m = 3 pass of the LDS-DMA fold per table
+void launch_fold3_tables(const void* const s[4], void* const d[4], size_t outlen, const uint64_t* r3, const uint64_t two24[4], void* wbuf,
+                         void* partials, hipStream_t st, const DmaGates& gates) {
+    ChalWide ch;
+    for (int l = 0; l < kMaxFoldBatch; ++l) ch.r[l] = l < 3 ? to_fq(r3 + 4 * l) : fq{};
+    ch.two24 = to_fq(two24);
+    hipLaunchKernelGGL(k_eq_weights28, dim3(1), dim3(kThreads), 0, st, ch, 3, (u32*)wbuf);
+    const bool stream_stores = gates.wide_stream_from_log < 63 && outlen >= ((size_t)1 << std::max(gates.wide_stream_from_log, 0));
+    size_t per = (outlen / 64 + 3) / 4;
+    if (per > 1024) per = 1024;
+    g_forms |= kFormFold3Dma;
+    for (int k = 0; k < 4; ++k) {
+        if (stream_stores)
+            hipLaunchKernelGGL((k_multifold_wide_dma<true, 4>), dim3((unsigned)per), dim3(kThreads), 0, st, (const fq*)s[k], (fq*)d[k], outlen,
+                               (const u32*)wbuf, 3, 0, (fq*)partials);
+        else
+            hipLaunchKernelGGL((k_multifold_wide_dma<false, 4>), dim3((unsigned)per), dim3(kThreads), 0, st, (const fq*)s[k], (fq*)d[k], outlen,
+                               (const u32*)wbuf, 3, 0, (fq*)partials);
+    }
 }
 void launch_gather4(const void* const t[4], size_t n, void* out, hipStream_t st) {
     Tab4 T;

@@ -832,7 +832,47 @@ static void host_round_pair_from_sum9(zk_transcript* tr, const Fq S[9], uint64_t
     zkh::store(rs + 4, s2);
 }
 
-// two rounds per device pass
+// the host part of K rounds from the cross sums P[term][e][e'] = sum_j F_e[j] G_e'[j] (e, e' < 2^K index the K top variables, the
+// first to bind on the most significant bit; kernels.hip, k_cross64_mfma).  With x the point of the K variables,
+// sum_j F(x, j) G(x, j) = sum_{e,e'} eq(x, e) eq(x, e') P[e][e'], so round i (r_0..r_{i-1} bound, X free, the rest y boolean) reads
+// only the entries whose remaining bits agree:  ev(X) = sum_y sum_{a,a'} L_a(X) L_a'(X) Q[(a,y)][(a',y)],  L_0 = 1 - X, L_1 = X,
+// and binding r contracts Q's top bit on both sides.  Exact arithmetic: the evaluations are the field elements prover.rs:93-100 sums.
+static void host_rounds_from_cross(zk_transcript* tr, int K, const Fq* P /* [2][4^K] */, uint64_t* coeffs_out /* K x 3 */, uint64_t* rs /* K x 4 */) {
+    size_t n = (size_t)1 << K;
+    std::vector<Fq> Q(P, P + 2 * n * n), Qn;
+    for (int i = 0; i < K; ++i) {
+        const size_t h = n / 2;
+        Fq ev[3] = {zkh::zero(), zkh::zero(), zkh::zero()};
+        for (int t = 0; t < 2; ++t) {
+            const Fq* q = Q.data() + (size_t)t * n * n;
+            for (size_t y = 0; y < h; ++y) {
+                const Fq q00 = q[y * n + y], q01 = q[y * n + h + y], q10 = q[(h + y) * n + y], q11 = q[(h + y) * n + h + y];
+                ev[0] = zkh::add(ev[0], q00);
+                ev[1] = zkh::add(ev[1], q11);
+                // X = 2: L_0 = -1, L_1 = 2
+                const Fq cross = zkh::add(q01, q10), q11x2 = zkh::add(q11, q11);
+                ev[2] = zkh::add(ev[2], zkh::sub(zkh::add(q00, zkh::add(q11x2, q11x2)), zkh::add(cross, cross)));
+            }
+        }
+        const Fq r = host_round_deg2(tr, ev, coeffs_out + 12 * i);
+        zkh::store(rs + 4 * i, r);
+        const Fq omr = zkh::sub(zkh::one(), r);
+        const Fq c00 = zkh::mul(omr, omr), c01 = zkh::mul(omr, r), c11 = zkh::mul(r, r);
+        Qn.assign(2 * h * h, zkh::zero());
+        for (int t = 0; t < 2; ++t) {
+            const Fq* q = Q.data() + (size_t)t * n * n;
+            Fq* o = Qn.data() + (size_t)t * h * h;
+            for (size_t y = 0; y < h; ++y)
+                for (size_t y2 = 0; y2 < h; ++y2)
+                    o[y * h + y2] = zkh::add(zkh::add(zkh::mul(c00, q[y * n + y2]), zkh::mul(c01, zkh::add(q[y * n + h + y2], q[(h + y) * n + y2]))),
+                                             zkh::mul(c11, q[(h + y) * n + h + y2]));
+        }
+        Q.swap(Qn);
+        n = h;
+    }
+}
+
+// two (nine sums) or three (8 x 8 cross sums) rounds per device pass
 static int prove_sum2x2_pairs(zk_ctx* c, const void* const tables[4], size_t len, zk_transcript* tr, uint64_t* coeffs_out,
                               uint64_t* challenges_out, uint64_t* final_out) {
     int rc = set_device(c);
@@ -842,34 +882,50 @@ static int prove_sum2x2_pairs(zk_ctx* c, const void* const tables[4], size_t len
     size_t curlen = len;
     unsigned k = 0; // round index
     int pass = 0;
-    if (curlen > kHostTail) {
-        ProfScope ps(c, ZK_K_SUM9, (uint64_t)len * 32 * 4);
-        zkk::launch_sum9(cur, curlen / 4, c->two24, c->deg2_lazy_from_log, c->partials, c->sums_host_dev, c->stream, c->gates); // nine sums straight into pinned host memory
-    }
+    // the sums sweep over four tables of n entries; returns the rounds it serves (3: cross sums, 2: nine sums)
+    auto launch_sums = [&](const void* const t[4], size_t n) -> int {
+        ProfScope ps(c, ZK_K_SUM9, (uint64_t)n * 32 * 4);
+        const int tf = c->gates.deg2_triple_from_log;
+        if (tf < 63 && n >= 512 && n >= ((size_t)1 << std::max(tf, 0)) && zkk::cross64_fits(n / 8)) {
+            zkk::launch_cross64(t, n / 8, c->gates.deg2_triple_ring, c->partials, c->sums_host_dev, c->stream); // 128 cross sums straight into pinned host memory
+            return 3;
+        }
+        zkk::launch_sum9(t, n / 4, c->two24, c->deg2_lazy_from_log, c->partials, c->sums_host_dev, c->stream, c->gates); // nine sums, likewise
+        return 2;
+    };
+    int K = 0;
+    if (curlen > kHostTail) K = launch_sums(cur, curlen);
     while (curlen > kHostTail) {
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        Fq S[9];
-        for (int i = 0; i < 9; ++i) S[i] = zkh::load(c->sums_host + 4 * i);
-        uint64_t rs[8];
-        host_round_pair_from_sum9(tr, S, coeffs_out + 12 * k, rs);
-        if (challenges_out) std::memcpy(challenges_out + 4 * k, rs, 2 * kElem);
-        k += 2;
-        // bind both variables in one sweep, then the nine sums of the result unless the host takes over
-        const size_t outlen = curlen / 4;
+        uint64_t rs[12];
+        if (K == 3) {
+            Fq P[128];
+            for (int i = 0; i < 128; ++i) P[i] = zkh::load(c->sums_host + 4 * i);
+            host_rounds_from_cross(tr, 3, P, coeffs_out + 12 * k, rs);
+        } else {
+            Fq S[9];
+            for (int i = 0; i < 9; ++i) S[i] = zkh::load(c->sums_host + 4 * i);
+            host_round_pair_from_sum9(tr, S, coeffs_out + 12 * k, rs);
+        }
+        if (challenges_out) std::memcpy(challenges_out + 4 * k, rs, (size_t)K * kElem);
+        k += (unsigned)K;
+        // bind the K variables in one sweep, then the sums of the result unless the host takes over
+        const size_t outlen = curlen >> K;
         if ((rc = ensure_work(c, pass & 1, 4 * outlen * kElem))) return rc;
         void* dst[4];
         for (int t = 0; t < 4; ++t) dst[t] = (uint8_t*)c->work[pass & 1] + (size_t)t * outlen * kElem;
-        uint32_t w28[4 * 10];
-        eq_weights28(rs, 2, w28);
         {
             ProfScope ps(c, ZK_K_FOLD2X4_SUM9, (uint64_t)curlen * 32 * 4 + (uint64_t)outlen * 32 * 4);
-            zkk::launch_fold2_tables(cur, dst, outlen, w28, c->wide_w, c->partials, c->stream, c->gates);
+            if (K == 3) {
+                zkk::launch_fold3_tables(cur, dst, outlen, rs, c->two24, c->wide_w, c->partials, c->stream, c->gates);
+            } else {
+                uint32_t w28[4 * 10];
+                eq_weights28(rs, 2, w28);
+                zkk::launch_fold2_tables(cur, dst, outlen, w28, c->wide_w, c->partials, c->stream, c->gates);
+            }
         }
-        if (outlen > kHostTail) {
-            ProfScope ps(c, ZK_K_SUM9, (uint64_t)outlen * 32 * 4);
-            zkk::launch_sum9(dst, outlen / 4, c->two24, c->deg2_lazy_from_log, c->partials, c->sums_host_dev, c->stream, c->gates);
-        }
+        if (outlen > kHostTail) K = launch_sums(dst, outlen);
         for (int t = 0; t < 4; ++t) cur[t] = dst[t];
         curlen = outlen;
         ++pass;
@@ -1139,6 +1195,12 @@ int zk_ctx_set_deg2_lazy_sums(zk_ctx* c, int from_log) {
 int zk_ctx_set_deg2_mfma_sums(zk_ctx* c, int from_log) {
     if (!c || from_log < 0 || from_log > 64) return ZK_E_ARG;
     c->gates.sum9_mfma_from_log = from_log;
+    return ZK_OK;
+}
+int zk_ctx_set_deg2_triple(zk_ctx* c, int from_log, int ring) {
+    if (!c || from_log < 0 || from_log > 64 || (ring != 3 && ring != 4)) return ZK_E_ARG;
+    c->gates.deg2_triple_from_log = from_log;
+    c->gates.deg2_triple_ring = ring;
     return ZK_OK;
 }
 int zk_ctx_set_deg2_rounds_per_pass(zk_ctx* c, int rounds) {
