@@ -373,6 +373,10 @@ int zk_ctx_set_deg2_mfma_sums(zk_ctx *ctx, int from_log);
  * sum_j F_e[j] G_e'[j] of both terms on the matrix cores, the host runs three rounds on them, one fold binds the three variables.
  * ring = 3 or 4 LDS tiles in the sweep.  An execution schedule: proof bytes do not depend on it. */
 int zk_ctx_set_deg2_triple(zk_ctx *ctx, int from_log, int ring);
+/* Degree-2 prover, two rounds per pass: while the folded tables have fewer than 2^below_log entries (0 = never) the two-variable fold
+ * (prover.rs:131-139, twice) and the nine sums of its result (the next two rounds' prover.rs:89-107) are one kernel -- GKR layer
+ * tables are cache-resident and a pass is bound by launches and per-lane chains, not by bytes.  Proof bytes do not depend on it. */
+int zk_ctx_set_deg2_fused(zk_ctx *ctx, int below_log);
 enum { ZK_K_BLOCK_SUMS = 0, ZK_K_MULTIFOLD = 1, ZK_K_FOLD = 2, ZK_K_EVAL3 = 3, ZK_K_FOLD4_EVAL3 = 4, ZK_K_SUM9 = 5, ZK_K_FOLD2X4_SUM9 = 6, ZK_K_MULTIFOLD_WIDE = 7, ZK_K_MULTIFOLD_TAIL = 8,
        ZK_K_COUNT = 10 };
 /* per-kernel HIP-event timing of the launches made by the provers on this context */

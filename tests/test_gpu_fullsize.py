@@ -156,12 +156,16 @@ def test_sumcheck_2pow30_largest_benchmark_size():
 
 def test_sum2x2_2pow24_both_nine_sum_kernels_agree():
     """The unreduced-accumulation sweep (k_sum9_lazy, LDS-DMA ring), the per-product-reduction sweep and the matrix-core
-    sweep (k_sum16_mfma, the default from 2^22 quarter-entries) give the same proof bytes at full size."""
+    sweep (k_sum16_mfma), and the default schedule (three rounds per pass on the 8 x 8 cross sums of k_cross64_mfma, then fused small
+    passes) give the same proof bytes at full size."""
     proofs = []
-    for lazy_from, mfma_from in ((20, 64), (-1, 64), (20, 22)):
+    # (lazy_from, mfma_from, triple_from, fused_below); the last: the defaults (three rounds per pass from 2^21, fused small passes)
+    for lazy_from, mfma_from, triple_from, fused_below in ((20, 64, 64, 0), (-1, 64, 64, 0), (20, 22, 64, 0), (18, 22, 21, 20)):
         ctx = zk_amd.Context(0)
         ctx.set_deg2_lazy_sums(lazy_from)
         ctx.set_deg2_mfma_sums(mfma_from)
+        ctx.set_deg2_triple(triple_from, 4)
+        ctx.set_deg2_fused(fused_below)
         tabs = [MLE.generate(SEED + 80 + k, 1 << 24, ctx=ctx) for k in range(4)]
         f = zk_amd.SumPolynomial([zk_amd.ProductPolynomial(tabs[:2]), zk_amd.ProductPolynomial(tabs[2:])])
         proof, pts = zk_amd.SumcheckProver.generate_proof_for_partial_verify(O.fq1(0), f, zk_amd.Transcript())
@@ -194,9 +198,12 @@ def test_constant_tables_of_p_minus_1_worst_case_limbs():
     del poly
     proofs = []
     m = 1 << 23
-    for lazy_from, mfma_from in ((18, 64), (-1, 64), (18, 0)):  # the last: every sweep on the matrix cores
+    # the last two: every sweep on the matrix cores (nine sums; 8 x 8 cross sums with three rounds per pass)
+    for lazy_from, mfma_from, triple_from, fused_below in ((18, 64, 64, 0), (-1, 64, 64, 0), (18, 0, 64, 0), (18, 0, 0, 20)):
         ctx.set_deg2_lazy_sums(lazy_from)
         ctx.set_deg2_mfma_sums(mfma_from)
+        ctx.set_deg2_triple(triple_from, 4)
+        ctx.set_deg2_fused(fused_below)
         tabs = [MLE(np.ascontiguousarray(np.broadcast_to(pm1, (m, 4))), ctx=ctx) for _ in range(4)]
         f = zk_amd.SumPolynomial([zk_amd.ProductPolynomial(tabs[:2]), zk_amd.ProductPolynomial(tabs[2:])])
         proof, pts = zk_amd.SumcheckProver.generate_proof_for_partial_verify(O.fq1(0), f, zk_amd.Transcript())

@@ -319,6 +319,7 @@ def test_sum2x2_both_schedules_give_the_oracle_proof(rounds_per_pass, lazy_from)
     c = zk_amd.Context(0)
     c.set_deg2_rounds_per_pass(rounds_per_pass)
     c.set_deg2_lazy_sums(lazy_from)
+    c.set_deg2_fused(0)        # every sweep through the nine-sum kernel under test (the fused form has its own test)
     for log_n in (2, 3, 6, 7, 8, 9, 11, 12, 14, 17):
         n = 1 << log_n
         tabs = [O.gen_table(SEED + 90 + k, 0, n) for k in range(4)]
@@ -408,6 +409,7 @@ def test_sum2x2_dma_two_variable_fold_vs_oracle(log_n, stream_stores, lazy_from)
     c = zk_amd.Context(0)
     c.set_dma_gates(27, 0 if stream_stores else 64, 0)
     c.set_deg2_lazy_sums(lazy_from)
+    c.set_deg2_fused(0)        # separate fold and sums launches: the forms under test
     n = 1 << log_n
     tabs = [O.gen_table(SEED + 180 + k, 0, n) for k in range(4)]
     m = [MLE(t, ctx=c) for t in tabs]
@@ -565,6 +567,7 @@ def test_mfma_wide_fold_on_extreme_bytes(fill):
 def test_sum2x2_mfma_nine_sums_vs_oracle(log_n):
     c = zk_amd.Context(0)
     c.set_deg2_mfma_sums(0)   # every sweep whose quarter-tables are whole 64-entry rows
+    c.set_deg2_fused(0)
     n = 1 << log_n
     tabs = [O.gen_table(SEED + 220 + k, 0, n) for k in range(4)]
     m = [MLE(t, ctx=c) for t in tabs]
@@ -573,6 +576,29 @@ def test_sum2x2_mfma_nine_sums_vs_oracle(log_n):
     c.forms_used()
     proof, pts = zk_amd.SumcheckProver.generate_proof_for_partial_verify(O.fq1(5), f, tr)
     assert "sum9_mfma" in c.forms_used()
+    ocoeffs, och = O.sumcheck_prove_sum([[tabs[0], tabs[1]], [tabs[2], tabs[3]]], O.fq1(5), otr)
+    assert np.array_equal(proof.round_polys, ocoeffs), log_n
+    assert np.array_equal(pts, och) and tr.peek_digest() == otr.peek_digest()
+
+
+# ---- fold + nine sums in one kernel (k_fold2_sum9: small, cache-resident tables) ---------------------------------------------------
+@pytest.mark.parametrize("fused_below", [0, 64])
+@pytest.mark.parametrize("log_n", [7, 8, 9, 10, 12, 13, 15, 16, 18])
+def test_sum2x2_fused_fold_and_sums_vs_oracle(log_n, fused_below):
+    """fused_below = 64: every two-round pass that still needs sums runs k_fold2_sum9; 0: never (separate fold and sums launches).
+    Same proof bytes as the oracle either way."""
+    c = zk_amd.Context(0)
+    c.set_deg2_fused(fused_below)
+    c.set_deg2_triple(64, 3)
+    n = 1 << log_n
+    tabs = [O.gen_table(SEED + 300 + k, 0, n) for k in range(4)]
+    m = [MLE(t, ctx=c) for t in tabs]
+    f = zk_amd.SumPolynomial([zk_amd.ProductPolynomial(m[:2]), zk_amd.ProductPolynomial(m[2:])])
+    tr, otr = zk_amd.Transcript(), O.OTranscript()
+    c.forms_used()
+    proof, pts = zk_amd.SumcheckProver.generate_proof_for_partial_verify(O.fq1(5), f, tr)
+    forms = c.forms_used()
+    assert ("fold2_sum9" in forms) == (fused_below == 64 and log_n >= 9), forms
     ocoeffs, och = O.sumcheck_prove_sum([[tabs[0], tabs[1]], [tabs[2], tabs[3]]], O.fq1(5), otr)
     assert np.array_equal(proof.round_polys, ocoeffs), log_n
     assert np.array_equal(pts, och) and tr.peek_digest() == otr.peek_digest()
@@ -635,6 +661,7 @@ def test_sum2x2_three_rounds_per_pass_extreme_bytes(fill):
 def test_sum2x2_mfma_nine_sums_extreme_bytes(fill):
     c = zk_amd.Context(0)
     c.set_deg2_mfma_sums(0)
+    c.set_deg2_fused(0)
     n = 1 << 12
 
     def const_table(raw):

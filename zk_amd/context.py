@@ -73,6 +73,10 @@ class Context:
         """Degree-2 prover: nine-sum sweeps over >= 2^from_log quarter-entries run on the matrix cores (64 = never)."""
         check(lib().zk_ctx_set_deg2_mfma_sums(self.h, from_log))
 
+    def set_deg2_fused(self, below_log: int = 20):
+        """Degree-2 prover: fold + nine sums of the result in one kernel while the folded tables have < 2^below_log entries (0 = never)."""
+        check(lib().zk_ctx_set_deg2_fused(self.h, below_log))
+
     def set_deg2_triple(self, from_log: int = 64, ring: int = 3):
         """Degree-2 prover: passes over tables of >= 2^from_log entries serve three rounds each (8 x 8 cross sums per term on the
         matrix cores + one three-variable fold); 64 = never.  ring = LDS tiles of the sweep (3 or 4)."""

@@ -66,18 +66,21 @@ namespace {
 void build_eq(zk_ctx* c, void* out, int k, const uint64_t* x, const Fq& scale, void* hi, void* lo) {
     const int k_lo = k / 2, k_hi = k - k_lo;
     const Fq one = zkh::one();
-    zkk::launch_eq_small(hi, k_hi, x, scale.l, c->stream);
-    zkk::launch_eq_small(lo, k_lo, x + 4 * k_hi, one.l, c->stream);
+    void* const o[2] = {hi, lo};
+    const int kk[2] = {k_hi, k_lo};
+    const uint64_t* const xx[2] = {x, x + 4 * k_hi};
+    const uint64_t* const ss[2] = {scale.l, one.l};
+    zkk::launch_eq_small_multi(2, o, kk, xx, ss, c->stream);
     zkk::launch_eq_outer(out, (size_t)1 << k, k_lo, hi, lo, nullptr, nullptr, c->stream);
 }
 // alpha * eq(xa, .) + beta * eq(xb, .)
 void build_eq2(zk_ctx* c, void* out, int k, const uint64_t* xa, const Fq& alpha, const uint64_t* xb, const Fq& beta, void* scratch4[4]) {
     const int k_lo = k / 2, k_hi = k - k_lo;
     const Fq one = zkh::one();
-    zkk::launch_eq_small(scratch4[0], k_hi, xa, alpha.l, c->stream);
-    zkk::launch_eq_small(scratch4[1], k_lo, xa + 4 * k_hi, one.l, c->stream);
-    zkk::launch_eq_small(scratch4[2], k_hi, xb, beta.l, c->stream);
-    zkk::launch_eq_small(scratch4[3], k_lo, xb + 4 * k_hi, one.l, c->stream);
+    const int kk[4] = {k_hi, k_lo, k_hi, k_lo};
+    const uint64_t* const xx[4] = {xa, xa + 4 * k_hi, xb, xb + 4 * k_hi};
+    const uint64_t* const ss[4] = {alpha.l, one.l, beta.l, one.l};
+    zkk::launch_eq_small_multi(4, scratch4, kk, xx, ss, c->stream);
     zkk::launch_eq_outer(out, (size_t)1 << k, k_lo, scratch4[0], scratch4[1], scratch4[2], scratch4[3], c->stream);
 }
 

@@ -17,6 +17,8 @@ void launch_circuit_layer(const void* in, void* out, const uint32_t* left, const
 // out[o] = scale * eq(x, o), o < 2^k, x[0] belongs to the most significant bit of o (k <= kMaxEqVars);
 // x: k elements as 4 x u64 Montgomery limbs each
 void launch_eq_small(void* out, int k, const uint64_t* x, const uint64_t scale[4], hipStream_t st);
+// up to four such half tables in ONE launch (they are independent; each is a chain of dependent products)
+void launch_eq_small_multi(int njobs, void* const out[], const int k[], const uint64_t* const x[], const uint64_t* const scale[], hipStream_t st);
 // out[o] = hiA[o >> log_lo] * loA[o & (2^log_lo - 1)]  (+ hiB[..] * loB[..] when hiB != NULL), o < n
 void launch_eq_outer(void* out, size_t n, int log_lo, const void* hiA, const void* loA, const void* hiB, const void* loB,
                      hipStream_t st);

@@ -51,17 +51,30 @@ __global__ void __launch_bounds__(kT) k_circuit_layer(const fq* __restrict__ in,
 }
 
 struct EqPts { fq x[kMaxEqVars]; fq scale; };
-__global__ void __launch_bounds__(kT) k_eq_small(fq* __restrict__ out, int k, EqPts P) {
+// up to four half tables in one launch (blockIdx.y = table): out[o] = scale * prod_m (bit (k-1-m) of o ? x[m] : 1 - x[m]).
+// A thread's k factors are multiplied as two interleaved chains (even and odd m): the kernel is one wave-step deep, so its time
+// is the dependent-product chain.
+struct EqJobs { fq* out[4]; int k[4]; EqPts P[4]; };
+__global__ void __launch_bounds__(kT) k_eq_small(EqJobs J) {
     const fq one = fq_one_mont();
+    const int job = blockIdx.y, k = J.k[job];
+    fq* __restrict__ out = J.out[job];
+    const EqPts& P = J.P[job];
     const size_t n = (size_t)1 << k, stride = (size_t)gridDim.x * kT;
     for (size_t o = (size_t)blockIdx.x * kT + threadIdx.x; o < n; o += stride) {
-        fq acc = P.scale;
-        for (int m = 0; m < k; ++m) { // x[m] <-> bit (k-1-m) of o
+        fq a = P.scale, b = one;
+        bool b_used = false;
+        for (int m = 0; m < k; m += 2) { // x[m] <-> bit (k-1-m) of o
             const fq xm = P.x[m];
-            const fq f = ((o >> (k - 1 - m)) & 1) ? xm : fq_sub(one, xm);
-            acc = fq_mul(acc, f);
+            a = fq_mul(a, ((o >> (k - 1 - m)) & 1) ? xm : fq_sub(one, xm));
+            if (m + 1 < k) {
+                const fq xn = P.x[m + 1];
+                const fq f = ((o >> (k - 2 - m)) & 1) ? xn : fq_sub(one, xn);
+                b = b_used ? fq_mul(b, f) : f;
+                b_used = true;
+            }
         }
-        fq_store(out + o, acc);
+        fq_store(out + o, b_used ? fq_mul(a, b) : a);
     }
 }
 
@@ -180,11 +193,24 @@ void launch_circuit_layer(const void* in, void* out, const uint32_t* left, const
                           size_t n_out, hipStream_t st) {
     hipLaunchKernelGGL(k_circuit_layer, dim3(grid1d(n_out)), dim3(kT), 0, st, (const fq*)in, (fq*)out, left, right, op, n_gates, n_out);
 }
+void launch_eq_small_multi(int njobs, void* const out[], const int k[], const uint64_t* const x[], const uint64_t* const scale[], hipStream_t st) {
+    EqJobs J{};
+    int kmax = 0;
+    for (int j = 0; j < njobs && j < 4; ++j) {
+        J.out[j] = (fq*)out[j];
+        J.k[j] = k[j];
+        for (int m = 0; m < kMaxEqVars; ++m) J.P[j].x[m] = m < k[j] ? to_fq4(x[j] + 4 * m) : to_fq4(scale[j]);
+        J.P[j].scale = to_fq4(scale[j]);
+        kmax = k[j] > kmax ? k[j] : kmax;
+    }
+    hipLaunchKernelGGL(k_eq_small, dim3(grid1d((size_t)1 << kmax), njobs), dim3(kT), 0, st, J);
+}
 void launch_eq_small(void* out, int k, const uint64_t* x, const uint64_t scale[4], hipStream_t st) {
-    EqPts P;
-    for (int m = 0; m < kMaxEqVars; ++m) P.x[m] = m < k ? to_fq4(x + 4 * m) : to_fq4(scale);
-    P.scale = to_fq4(scale);
-    hipLaunchKernelGGL(k_eq_small, dim3(grid1d((size_t)1 << k)), dim3(kT), 0, st, (fq*)out, k, P);
+    void* const o[1] = {out};
+    const int kk[1] = {k};
+    const uint64_t* const xx[1] = {x};
+    const uint64_t* const ss[1] = {scale};
+    launch_eq_small_multi(1, o, kk, xx, ss, st);
 }
 void launch_eq_outer(void* out, size_t n, int log_lo, const void* hiA, const void* loA, const void* hiB, const void* loB, hipStream_t st) {
     hipLaunchKernelGGL(k_eq_outer, dim3(grid1d(n)), dim3(kT), 0, st, (fq*)out, n, log_lo, (const fq*)hiA, (const fq*)loA, (const fq*)hiB,

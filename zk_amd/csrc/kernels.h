@@ -48,6 +48,7 @@ struct DmaGates {
     int sum9_mfma_from_log = 22;   // nine sums on the matrix cores (k_sum16_mfma) from 2^k quarter-entries (measured break-even); 64 = never
     int wide_mfma_depth = 2;       // its pipeline depth K (2..4): table rows of K steps in flight per wave
     int deg2_triple_from_log = 21; // degree-2 prover: three rounds per pass (k_cross64_mfma + m = 3 fold) on tables of >= 2^k entries; 64 = never
+    int deg2_fused_below_log = 20; // degree-2 prover: fold + nine sums in one kernel (k_fold2_sum9) for folded tables below 2^k entries; 0 = never
     int deg2_triple_ring = 4;      // its LDS ring: 3 or 4 tiles of 32 KiB
 };
 // out[b] (b < 2^log_ob) = sum of the b-th contiguous block of T (L entries); partials is scratch
@@ -98,6 +99,8 @@ void launch_cross64(const void* const t[4], size_t q, int ring, void* partials, 
 // multiple of 64); wbuf (>= 80 u32) and partials (>= 1024 elements) are scratch
 void launch_fold3_tables(const void* const s[4], void* const d[4], size_t outlen, const uint64_t* r3, const uint64_t two24[4], void* wbuf,
                          void* partials, hipStream_t st, const DmaGates& gates = DmaGates());
+// launch_fold2_tables followed by launch_sum9 on its result, as one kernel + the second stage (small, cache-resident tables; outlen >= 4)
+void launch_fold2_sum9(const void* const s[4], void* const d[4], size_t outlen, const uint32_t* w28, void* partials, void* out, hipStream_t st);
 // out[k*n + i] = t[k][i], k < 4, i < n
 void launch_gather4(const void* const t[4], size_t n, void* out, hipStream_t st);
 // out[(t * L + j) * world + q] = in[(q * ntab + t) * L + j]: the ranks' gathered local tables (rank-major) -> the remaining

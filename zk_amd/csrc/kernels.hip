@@ -1228,7 +1228,7 @@ __global__ void __launch_bounds__(64) k_sum9_from_p16(const fq* __restrict__ in4
 // wave w keeps C[e = w][e' = 0..7] (128 accumulator registers) and the plain sums of rows F_w and G_w; a tile is 16 rows x 2 KiB,
 // staged by LDS-DMA through a ring of R tiles (R - 1 in flight; 32 R KiB of LDS: one workgroup per CU).
 // partials: [(term * gridDim.x + bx) * 80 + ...]: 64 values P_signed[e][e'] * 2^-256 (index 8 e + e'), then A_e (8), then B_e' (8).
-template <int R>
+template <int R, int DBG = 0>
 __global__ void __launch_bounds__(512) k_cross64_mfma(Tab4 T, size_t q, fq* __restrict__ partials) {
     constexpr int NE = 8;
     __shared__ u32x4 sh[R][2 * NE][128];
@@ -1271,7 +1271,7 @@ __global__ void __launch_bounds__(512) k_cross64_mfma(Tab4 T, size_t q, fq* __re
         if (t + R - 1 < nt) stage(t + R - 1); // into the slot every wave finished reading before this barrier
         const u32 tile = (u32)(uintptr_t)&sh[t % R][0][0];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) { // 32 quarter-indices per step
+        for (int ks = 0; ks < ((DBG & 1) ? 0 : 2); ++ks) { // 32 quarter-indices per step
             const u32 a0 = tile + (u32)w * 2048u + (u32)ks * 1024u + tr_off;  // row F_w
             const u32 b0 = tile + (u32)NE * 2048u + (u32)ks * 1024u + tr_off; // rows G_0 .. G_7
             u64 fa0, fa1, gb[NE][2];
@@ -1311,7 +1311,7 @@ __global__ void __launch_bounds__(512) k_cross64_mfma(Tab4 T, size_t q, fq* __re
                 acc[e] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, B, acc[e], 0, 0, 0);
             }
         }
-        { // plain sums: lane l adds entry l of rows F_w and G_w
+        if (!(DBG & 2)) { // plain sums: lane l adds entry l of rows F_w and G_w
             const u32x4 flo = sh[t % R][w][2 * lane], fhi = sh[t % R][w][2 * lane + 1];
             const u32x4 glo = sh[t % R][NE + w][2 * lane], ghi = sh[t % R][NE + w][2 * lane + 1];
             u32 c = 0;
@@ -1437,6 +1437,99 @@ __global__ void __launch_bounds__(kThreads) k_fold2_tables(Tab4 S, Tab4w D, size
         fq28_mac(a28, in2, W.w[2]);
         fq28_mac(a28, in3, W.w[3]);
         fq_store(dst + o, fq28_redc(a28));
+    }
+}
+
+// Small tables (GKR layers: <= 2^20 entries per table, L2-resident): a pass is bound by launch gaps and by each lane's serial chain,
+// not by bytes, so the two-variable fold and the nine sums of its result are ONE kernel.  A wave serves 16 next-level quarter-indices
+// j' of one term with FOUR lanes each: lane (e, jj) folds entry e q' + j' of both factor tables (8 loads, 8 unreduced products, 2
+// reductions), stores them, and the four lanes of a j' exchange their folded values through LDS (wave-private: program order, no
+// barrier).  Lane e < 3 then forms the three products of Y = e (operands picked by select, not by branch: the wave runs one code
+// path); lane e = 3 contributes zero.  Chain per lane ~1900 vector instructions instead of ~500 + ~1000 in two launches with a
+// second-stage launch between.  partials: [(term * gridDim.x + bx) * 9 + 3Y + t] (k_reduce9, ysplit = 0).
+__global__ void __launch_bounds__(kThreads) k_fold2_sum9(Tab4 S, Tab4w D, size_t outlen, W28<2> W, fq* __restrict__ partials) {
+    __shared__ u32x4 xch[kThreads / 64][2][4][16][2]; // [wave][factor][e][jj][half]: 4 KiB per wave
+    __shared__ fq red[kThreads / 64][9];
+    const int term = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int e = lane >> 4, jj = lane & 15;
+    const fq* __restrict__ F = S.t[2 * term];
+    const fq* __restrict__ G = S.t[2 * term + 1];
+    fq* __restrict__ DF = D.t[2 * term];
+    fq* __restrict__ DG = D.t[2 * term + 1];
+    const size_t qn = outlen >> 2; // next-level quarter length
+    fq acc[3] = {fq_zero(), fq_zero(), fq_zero()};
+    const size_t stride = (size_t)gridDim.x * 64; // j' per grid step
+    for (size_t j0 = (size_t)blockIdx.x * 64 + (size_t)wave * 16; j0 < qn; j0 += stride) { // wave-uniform
+        const size_t j = j0 + jj;
+        const bool live = j < qn;
+        const size_t o = (size_t)e * qn + (live ? j : 0);
+        fq f[4], g[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            f[b] = fq_load(F + (size_t)b * outlen + o);
+            g[b] = fq_load(G + (size_t)b * outlen + o);
+        }
+        u64 a28[20];
+#pragma unroll
+        for (int k = 0; k < 20; ++k) a28[k] = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) fq28_mac(a28, f[b], W.w[b]);
+        const fq fo = fq28_redc(a28);
+#pragma unroll
+        for (int k = 0; k < 20; ++k) a28[k] = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) fq28_mac(a28, g[b], W.w[b]);
+        const fq go = fq28_redc(a28);
+        if (live) {
+            fq_store(DF + o, fo);
+            fq_store(DG + o, go);
+        }
+        xch[wave][0][e][jj][0] = u32x4{fo.v[0], fo.v[1], fo.v[2], fo.v[3]};
+        xch[wave][0][e][jj][1] = u32x4{fo.v[4], fo.v[5], fo.v[6], fo.v[7]};
+        xch[wave][1][e][jj][0] = u32x4{go.v[0], go.v[1], go.v[2], go.v[3]};
+        xch[wave][1][e][jj][1] = u32x4{go.v[4], go.v[5], go.v[6], go.v[7]};
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // wave-private exchange: every lane of the wave has written
+        // operands of Y = e: the b2 = 0 entries (e'' = 0, 2) for Y = 0, the b2 = 1 entries (1, 3) for Y = 1, 2 x[.][1] - x[.][0] for Y = 2
+        fq v0[2], v1[2];
+#pragma unroll
+        for (int fac = 0; fac < 2; ++fac) {
+            fq x[4];
+#pragma unroll
+            for (int ee = 0; ee < 4; ++ee) {
+                const u32x4 lo = xch[wave][fac][ee][jj][0], hi = xch[wave][fac][ee][jj][1];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { x[ee].v[k] = lo[k]; x[ee].v[4 + k] = hi[k]; }
+            }
+            const fq y20 = fq_sub(fq_dbl(x[1]), x[0]), y21 = fq_sub(fq_dbl(x[3]), x[2]);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                v0[fac].v[k] = e == 0 ? x[0].v[k] : (e == 1 ? x[1].v[k] : y20.v[k]);
+                v1[fac].v[k] = e == 0 ? x[2].v[k] : (e == 1 ? x[3].v[k] : y21.v[k]);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // values in registers before the next trip overwrites the exchange space
+        const fq d0 = fq_sub(v1[0], v0[0]), d1 = fq_sub(v1[1], v0[1]);
+        const fq p0 = fq_mul(v0[0], v0[1]), p1 = fq_mul(v1[0], v1[1]), p2 = fq_mul(d0, d1);
+        if (live && e < 3) {
+            acc[0] = fq_add(acc[0], p0);
+            acc[1] = fq_add(acc[1], p1);
+            acc[2] = fq_add(acc[2], p2);
+        }
+    }
+    // sums over the 16 lanes of each e, then over the waves
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        fq a = acc[t];
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) a = fq_add(a, fq_shfl_down(a, off));
+        if (jj == 0 && e < 3) red[wave][3 * e + t] = a;
+    }
+    __syncthreads();
+    if (threadIdx.x < 9) {
+        fq t = red[0][threadIdx.x];
+#pragma unroll
+        for (int w = 1; w < kThreads / 64; ++w) t = fq_add(t, red[w][threadIdx.x]);
+        fq_store(&partials[((size_t)term * gridDim.x + blockIdx.x) * 9 + threadIdx.x], t);
     }
 }
 
@@ -1749,7 +1842,7 @@ void launch_sum9(const void* const t[4], size_t q, const uint64_t fix24[4], int 
     if (lazy_from_log >= 0 && lazy_from_log < 63 && q >= 64 && q >= ((size_t)1 << lazy_from_log)) { // large: unreduced accumulation, one wave per Y
         size_t gx = (q + 63) / 64;
         if (gx > (size_t)kMaxBlocks9) gx = kMaxBlocks9;
-        fq* u = (fq*)partials + (size_t)18 * kMaxBlocks9; // nine U sums, behind the partials
+        fq* u = (fq*)partials + (size_t)18 * gx; // nine U sums, behind the partials
         g_forms |= kFormSum9Lazy;
         hipLaunchKernelGGL(k_sum9_lazy, dim3((unsigned)gx, 2), dim3(64, 9), 0, st, T, q, to_fq(fix24), (fq*)partials);
         hipLaunchKernelGGL(k_reduce9, dim3(9), dim3(kThreads), 0, st, (const fq*)partials, (int)gx, 1, u);
@@ -1779,6 +1872,11 @@ void launch_cross64(const void* const t[4], size_t q, int ring, void* partials, 
     qn.v[0] = (u32)q;
     qn.v[1] = (u32)((u64)q >> 32);
     g_forms |= kFormCross64;
+    static const int dbg = getenv("ZK_CROSS_DBG") ? atoi(getenv("ZK_CROSS_DBG")) : 0;
+    if (dbg == 1) hipLaunchKernelGGL((k_cross64_mfma<4, 1>), dim3((unsigned)gx, 2), dim3(512), 0, st, T, q, (fq*)partials);
+    else if (dbg == 2) hipLaunchKernelGGL((k_cross64_mfma<4, 2>), dim3((unsigned)gx, 2), dim3(512), 0, st, T, q, (fq*)partials);
+    else if (dbg == 3) hipLaunchKernelGGL((k_cross64_mfma<4, 3>), dim3((unsigned)gx, 2), dim3(512), 0, st, T, q, (fq*)partials);
+    else
     if (ring == 4) hipLaunchKernelGGL((k_cross64_mfma<4>), dim3((unsigned)gx, 2), dim3(512), 0, st, T, q, (fq*)partials);
     else hipLaunchKernelGGL((k_cross64_mfma<3>), dim3((unsigned)gx, 2), dim3(512), 0, st, T, q, (fq*)partials);
     hipLaunchKernelGGL(k_reduce_cross, dim3(160), dim3(kThreads), 0, st, (const fq*)partials, (int)gx, 80, red);
@@ -1846,6 +1944,21 @@ void launch_fold2_tables(const void* const s[4], void* const d[4], size_t outlen
     if (gx > (size_t)kMaxBlocks) gx = kMaxBlocks;
     g_forms |= kFormFold2Reg;
     hipLaunchKernelGGL(k_fold2_tables, dim3((unsigned)gx, 4), dim3(kThreads), 0, st, S, D, outlen, W);
+}
+// the fold of launch_fold2_tables and the nine sums of its result (launch_sum9 on d[]) in one launch + the second stage: small tables
+void launch_fold2_sum9(const void* const s[4], void* const d[4], size_t outlen, const uint32_t* w28, void* partials, void* out, hipStream_t st) {
+    Tab4 S;
+    Tab4w D;
+    for (int k = 0; k < 4; ++k) { S.t[k] = (const fq*)s[k]; D.t[k] = (fq*)d[k]; }
+    W28<2> W;
+    for (int b = 0; b < 4; ++b)
+        for (int j = 0; j < 10; ++j) W.w[b][j] = w28[b * 10 + j];
+    size_t gx = (outlen / 4 + 63) / 64;
+    if (gx < 1) gx = 1;
+    if (gx > (size_t)kMaxBlocks9) gx = kMaxBlocks9;
+    g_forms |= kFormFold2Sum9;
+    hipLaunchKernelGGL(k_fold2_sum9, dim3((unsigned)gx, 2), dim3(kThreads), 0, st, S, D, outlen, W, (fq*)partials);
+    hipLaunchKernelGGL(k_reduce9, dim3(9), dim3(kThreads), 0, st, (const fq*)partials, (int)gx, 0, (fq*)out);
 }
 void launch_interleave(const void* in, void* out, int world, int ntab, size_t L, hipStream_t st) {
     hipLaunchKernelGGL(k_interleave, dim3(grid_for((size_t)world * ntab * L)), dim3(kThreads), 0, st, (const fq*)in, (fq*)out, (unsigned)world,

@@ -915,17 +915,26 @@ static int prove_sum2x2_pairs(zk_ctx* c, const void* const tables[4], size_t len
         if ((rc = ensure_work(c, pass & 1, 4 * outlen * kElem))) return rc;
         void* dst[4];
         for (int t = 0; t < 4; ++t) dst[t] = (uint8_t*)c->work[pass & 1] + (size_t)t * outlen * kElem;
-        {
+        const int fb = c->gates.deg2_fused_below_log;
+        if (K == 2 && outlen > kHostTail && fb > 0 && outlen < ((size_t)1 << std::min(fb, 62))) {
+            // small tables: the fold and the nine sums of its result in one launch
             ProfScope ps(c, ZK_K_FOLD2X4_SUM9, (uint64_t)curlen * 32 * 4 + (uint64_t)outlen * 32 * 4);
-            if (K == 3) {
-                zkk::launch_fold3_tables(cur, dst, outlen, rs, c->two24, c->wide_w, c->partials, c->stream, c->gates);
-            } else {
-                uint32_t w28[4 * 10];
-                eq_weights28(rs, 2, w28);
-                zkk::launch_fold2_tables(cur, dst, outlen, w28, c->wide_w, c->partials, c->stream, c->gates);
+            uint32_t w28[4 * 10];
+            eq_weights28(rs, 2, w28);
+            zkk::launch_fold2_sum9(cur, dst, outlen, w28, c->partials, c->sums_host_dev, c->stream);
+        } else {
+            {
+                ProfScope ps(c, ZK_K_FOLD2X4_SUM9, (uint64_t)curlen * 32 * 4 + (uint64_t)outlen * 32 * 4);
+                if (K == 3) {
+                    zkk::launch_fold3_tables(cur, dst, outlen, rs, c->two24, c->wide_w, c->partials, c->stream, c->gates);
+                } else {
+                    uint32_t w28[4 * 10];
+                    eq_weights28(rs, 2, w28);
+                    zkk::launch_fold2_tables(cur, dst, outlen, w28, c->wide_w, c->partials, c->stream, c->gates);
+                }
             }
+            if (outlen > kHostTail) K = launch_sums(dst, outlen);
         }
-        if (outlen > kHostTail) K = launch_sums(dst, outlen);
         for (int t = 0; t < 4; ++t) cur[t] = dst[t];
         curlen = outlen;
         ++pass;
@@ -1195,6 +1204,11 @@ int zk_ctx_set_deg2_lazy_sums(zk_ctx* c, int from_log) {
 int zk_ctx_set_deg2_mfma_sums(zk_ctx* c, int from_log) {
     if (!c || from_log < 0 || from_log > 64) return ZK_E_ARG;
     c->gates.sum9_mfma_from_log = from_log;
+    return ZK_OK;
+}
+int zk_ctx_set_deg2_fused(zk_ctx* c, int below_log) {
+    if (!c || below_log < 0 || below_log > 64) return ZK_E_ARG;
+    c->gates.deg2_fused_below_log = below_log;
     return ZK_OK;
 }
 int zk_ctx_set_deg2_triple(zk_ctx* c, int from_log, int ring) {
