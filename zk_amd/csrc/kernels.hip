@@ -1841,7 +1841,9 @@ void launch_sum9(const void* const t[4], size_t q, const uint64_t fix24[4], int 
     }
     if (lazy_from_log >= 0 && lazy_from_log < 63 && q >= 64 && q >= ((size_t)1 << lazy_from_log)) { // large: unreduced accumulation, one wave per Y
         size_t gx = (q + 63) / 64;
-        if (gx > (size_t)kMaxBlocks9) gx = kMaxBlocks9;
+        // 256 workgroups per term (two per CU): this kernel serves the L2-resident sizes (GKR layers: 2^18 quarter-entries), where fewer,
+        // longer-running workgroups beat 1024 short ones (GKR config-5 layers 13.4 -> 12.6 ms, 4 x 2^20 prove 0.389 -> 0.358 ms)
+        if (gx > 256) gx = 256;
         fq* u = (fq*)partials + (size_t)18 * gx; // nine U sums, behind the partials
         g_forms |= kFormSum9Lazy;
         hipLaunchKernelGGL(k_sum9_lazy, dim3((unsigned)gx, 2), dim3(64, 9), 0, st, T, q, to_fq(fix24), (fq*)partials);
@@ -1955,7 +1957,7 @@ void launch_fold2_sum9(const void* const s[4], void* const d[4], size_t outlen, 
         for (int j = 0; j < 10; ++j) W.w[b][j] = w28[b * 10 + j];
     size_t gx = (outlen / 4 + 63) / 64;
     if (gx < 1) gx = 1;
-    if (gx > (size_t)kMaxBlocks9) gx = kMaxBlocks9;
+    if (gx > (size_t)kMaxBlocks9) gx = kMaxBlocks9; // 512 and 256 measure the same on GKR config 5
     g_forms |= kFormFold2Sum9;
     hipLaunchKernelGGL(k_fold2_sum9, dim3((unsigned)gx, 2), dim3(kThreads), 0, st, S, D, outlen, W, (fq*)partials);
     hipLaunchKernelGGL(k_reduce9, dim3(9), dim3(kThreads), 0, st, (const fq*)partials, (int)gx, 0, (fq*)out);
