@@ -1226,9 +1226,10 @@ __global__ void __launch_bounds__(64) k_sum9_from_p16(const fq* __restrict__ in4
 // the tables are read 8/7 + (9/8)(8/7) = 2.43 times instead of 3.0 (two rounds per pass).  Same scheme as k_sum16_mfma -- bytes
 // as signed i8, v_mfma_i32_32x32x32_i8 with the contraction over j, operands by ds_read_b64_tr_b8 -- with eight waves per workgroup:
 // wave w keeps C[e = w][e' = 0..7] (128 accumulator registers) and the plain sums of rows F_w and G_w; a tile is 16 rows x 2 KiB,
-// staged by LDS-DMA through a ring of R tiles (R - 1 in flight; 32 R KiB of LDS: one workgroup per CU).
+// staged by LDS-DMA through a ring of R tiles (R - 1 in flight; 32 R KiB of LDS: one workgroup per CU).  Measured at 4 x 2^26: 5.9 TB/s;
+// the same ring with the matrix and LDS work removed 6.2, two 2-tile workgroups per CU 5.3, default instead of nt load policy 5.6.
 // partials: [(term * gridDim.x + bx) * 80 + ...]: 64 values P_signed[e][e'] * 2^-256 (index 8 e + e'), then A_e (8), then B_e' (8).
-template <int R, int DBG = 0>
+template <int R>
 __global__ void __launch_bounds__(512) k_cross64_mfma(Tab4 T, size_t q, fq* __restrict__ partials) {
     constexpr int NE = 8;
     __shared__ u32x4 sh[R][2 * NE][128];
@@ -1271,7 +1272,7 @@ __global__ void __launch_bounds__(512) k_cross64_mfma(Tab4 T, size_t q, fq* __re
         if (t + R - 1 < nt) stage(t + R - 1); // into the slot every wave finished reading before this barrier
         const u32 tile = (u32)(uintptr_t)&sh[t % R][0][0];
 #pragma unroll
-        for (int ks = 0; ks < ((DBG & 1) ? 0 : 2); ++ks) { // 32 quarter-indices per step
+        for (int ks = 0; ks < 2; ++ks) { // 32 quarter-indices per step
             const u32 a0 = tile + (u32)w * 2048u + (u32)ks * 1024u + tr_off;  // row F_w
             const u32 b0 = tile + (u32)NE * 2048u + (u32)ks * 1024u + tr_off; // rows G_0 .. G_7
             u64 fa0, fa1, gb[NE][2];
@@ -1311,7 +1312,7 @@ __global__ void __launch_bounds__(512) k_cross64_mfma(Tab4 T, size_t q, fq* __re
                 acc[e] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, B, acc[e], 0, 0, 0);
             }
         }
-        if (!(DBG & 2)) { // plain sums: lane l adds entry l of rows F_w and G_w
+        { // plain sums: lane l adds entry l of rows F_w and G_w
             const u32x4 flo = sh[t % R][w][2 * lane], fhi = sh[t % R][w][2 * lane + 1];
             const u32x4 glo = sh[t % R][NE + w][2 * lane], ghi = sh[t % R][NE + w][2 * lane + 1];
             u32 c = 0;
@@ -1874,11 +1875,6 @@ void launch_cross64(const void* const t[4], size_t q, int ring, void* partials, 
     qn.v[0] = (u32)q;
     qn.v[1] = (u32)((u64)q >> 32);
     g_forms |= kFormCross64;
-    static const int dbg = getenv("ZK_CROSS_DBG") ? atoi(getenv("ZK_CROSS_DBG")) : 0;
-    if (dbg == 1) hipLaunchKernelGGL((k_cross64_mfma<4, 1>), dim3((unsigned)gx, 2), dim3(512), 0, st, T, q, (fq*)partials);
-    else if (dbg == 2) hipLaunchKernelGGL((k_cross64_mfma<4, 2>), dim3((unsigned)gx, 2), dim3(512), 0, st, T, q, (fq*)partials);
-    else if (dbg == 3) hipLaunchKernelGGL((k_cross64_mfma<4, 3>), dim3((unsigned)gx, 2), dim3(512), 0, st, T, q, (fq*)partials);
-    else
     if (ring == 4) hipLaunchKernelGGL((k_cross64_mfma<4>), dim3((unsigned)gx, 2), dim3(512), 0, st, T, q, (fq*)partials);
     else hipLaunchKernelGGL((k_cross64_mfma<3>), dim3((unsigned)gx, 2), dim3(512), 0, st, T, q, (fq*)partials);
     hipLaunchKernelGGL(k_reduce_cross, dim3(160), dim3(kThreads), 0, st, (const fq*)partials, (int)gx, 80, red);
