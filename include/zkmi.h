@@ -308,6 +308,17 @@ int zk_circuit_gate_poly(zk_circuit *c, size_t layer_idx, int op, zk_mle **out);
 int zk_gkr_prove(zk_ctx *ctx, zk_circuit *circuit, zk_transcript *transcript, const zk_mle *inputs,
                  uint64_t *output_poly_out, uint64_t *w_evals_out, uint64_t *claims_out, uint64_t *coeffs_out,
                  double *layer_ms_out);
+/* The same proof from the ranks of the context's communicator (zk_comm_init_*; SURVEY.md 8e: "phase tables sharded on low bits; gate
+ * list partitioned").  Every rank passes the same circuit and inputs (replicated: the layer tables are small) and gets the same
+ * GKRProof; what is sharded is each layer's degree-2 sumcheck (gkr/src/prover.rs:128-141): rank q builds the folded-predicate tables
+ * for the indices that are q mod world and the ranks run zk_sumcheck_prove_sum2x2_sharded's loop on them.  gather_log >= 0 as there
+ * (the last rounds of each phase run replicated on the gathered tables, which is where W(u), W(v) of prover.rs:87-99 come from).
+ * Layers with fewer than two entries per rank run replicated.  ZK_E_COMM without a communicator.  A GKR layer at 2^20 gates is bound
+ * by launch latency, not by bytes: this entry point exists for layers too large for one GPU's latency budget, it is not faster at
+ * BASELINE config 5. */
+int zk_gkr_prove_sharded(zk_ctx *ctx, zk_circuit *circuit, zk_transcript *transcript, const zk_mle *inputs, int gather_log,
+                         uint64_t *output_poly_out, uint64_t *w_evals_out, uint64_t *claims_out, uint64_t *coeffs_out,
+                         double *layer_ms_out);
 
 /* GKRVerifier::verify_proof (gkr/src/verifier.rs:21-119); proof arrays as zk_gkr_prove returns them.  The
  * predicates are evaluated from the gate list (the reference rebuilds the dense tables, :39-40).  *ok_out =

@@ -280,3 +280,65 @@ def test_library_sharded_prover_without_transport_and_errors():
         oclaim, ocoeffs, och = O.sumcheck_prove(table)
         assert list(c) == list(oclaim) and np.array_equal(co, ocoeffs) and np.array_equal(ch, och)
     sharded.comm_destroy(ctx)
+
+
+# ---------------------------------------------------------------- the GKR layer prover over ranks (zk_gkr_prove_sharded)
+def _gkr_case(case):
+    import random
+    from test_gpu_gkr import CIRCUIT_GKR, random_circuit
+    if case == "reference":        # gkr_protocol.rs:67-94
+        return CIRCUIT_GKR, O.ints_to_mont([1, 2, 3, 4, 5, 6, 7, 8])
+    if case == "random":
+        return random_circuit([32, 32, 16, 32, 7], 11), O.gen_table(SEED + 11, 0, 32)
+    W, depth = 1 << 10, 3          # wide: beyond the dense oracle, compared with the single-GPU prover
+    rng = random.Random(9)
+    return [[((2 * g + 3 * d) % W, (5 * g + 1) % W, rng.randrange(2)) for g in range(W)] for d in range(depth)], O.gen_table(SEED + 99, 0, W)
+
+
+def _worker_gkr(rank, world, port, case, gather_log, outdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from test_gpu_gkr import mk, proof_bytes
+        ctx = zk_amd.Context(0)
+        assert sharded.comm_init(ctx, dist, None, "host") == "host"
+        layers, inputs = _gkr_case(case)
+        tr = zk_amd.Transcript()
+        proof = zk_amd.GKRProver.generate_proof(mk(layers, ctx), tr, zk_amd.MultiLinearPolynomial(inputs, ctx=ctx), sharded_gather_log=gather_log)
+        with open(os.path.join(outdir, f"G{rank}.bin"), "wb") as f:
+            f.write(tr.peek_digest() + proof_bytes(proof, ctx))
+        sharded.comm_destroy(ctx)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,case,gather_log", [(2, "reference", 0), (2, "random", 1), (4, "random", 2), (2, "wide", 5), (4, "wide", 3), (8, "wide", 13)])
+def test_library_sharded_gkr_prover_ranks_on_one_gpu(tmp_path, world, case, gather_log):
+    """zk_gkr_prove_sharded: every layer's sumcheck over tables sharded on their low index bits (gate list partitioned by input
+    index), exchange through the host all-gather callback over gloo.  Every rank's proof and final transcript state equal the
+    single-GPU prover's, which test_gpu_gkr.py pins to the dense oracle; the small cases are compared with the oracle here too."""
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    from test_gpu_gkr import mk, proof_bytes
+    mp.spawn(_worker_gkr, args=(world, _free_port(), case, gather_log, str(tmp_path)), nprocs=world, join=True)
+    layers, inputs = _gkr_case(case)
+    ctx = zk_amd.default_context()
+    tr = zk_amd.Transcript()
+    proof = zk_amd.GKRProver.generate_proof(mk(layers, ctx), tr, inputs)
+    want = tr.peek_digest() + proof_bytes(proof, ctx)
+    if case != "wide":
+        oc = O.OCircuit(layers)
+        otr = O.OTranscript()
+        oblob, _ = O.gkr_prove(oc, otr, inputs).serialize()
+        assert want == otr.peek_digest() + oblob
+    for r in range(world):
+        assert (tmp_path / f"G{r}.bin").read_bytes() == want, f"rank {r}"
+
+
+def test_sharded_gkr_needs_a_communicator():
+    from test_gpu_gkr import CIRCUIT_GKR, mk
+    ctx = zk_amd.Context(0)
+    with pytest.raises(zk_amd.ZkError) as ei:
+        zk_amd.GKRProver.generate_proof(mk(CIRCUIT_GKR, ctx), zk_amd.Transcript(), O.ints_to_mont([1, 2, 3, 4, 5, 6, 7, 8]), sharded_gather_log=3)
+    assert ei.value.status == 10

@@ -106,6 +106,7 @@ SYMBOLS = [
     ("zk_circuit_evaluate", C.c_int, [_VP, _VP, C.POINTER(_VP)]),
     ("zk_circuit_gate_poly", C.c_int, [_VP, C.c_size_t, C.c_int, C.POINTER(_VP)]),
     ("zk_gkr_prove", C.c_int, [_VP, _VP, _VP, _VP, u64p, u64p, u64p, u64p, C.POINTER(C.c_double)]),
+    ("zk_gkr_prove_sharded", C.c_int, [_VP, _VP, _VP, _VP, C.c_int, u64p, u64p, u64p, u64p, C.POINTER(C.c_double)]),
     ("zk_gkr_verify", C.c_int, [_VP, _VP, _VP, _VP, u64p, C.c_size_t, u64p, u64p, u64p, C.POINTER(C.c_int)]),
     ("zk_ctx_set_fold_batch", C.c_int, [_VP, C.c_int, C.c_int]),
     ("zk_ctx_set_wide_fold", C.c_int, [_VP, C.c_int, C.c_int, C.c_int]),

@@ -258,9 +258,17 @@ int zk_mle_add(const zk_mle* a, const zk_mle* b, zk_mle** out) { // _add :241-25
     return finish_new(c, o, out, "add");
 }
 
+} // extern "C"
+
 // ---- GKRProver::generate_proof (gkr/src/prover.rs:24-154) ----------------------------------------
-int zk_gkr_prove(zk_ctx* c, zk_circuit* ci, zk_transcript* tr, const zk_mle* inputs, uint64_t* output_poly_out, uint64_t* w_evals_out,
-                 uint64_t* claims_out, uint64_t* coeffs_out, double* layer_ms_out) {
+// world > 1: this process is rank `rank` of a sharded prove (last row).  Circuit, inputs and the layer evaluations
+// are replicated (32 MiB per layer at 2^20 gates); what is sharded is each layer's sumcheck: rank q builds the phase tables for
+// the indices b (resp. c) that are q mod world -- the gates partitioned by their left (resp. right) input, tables sharded on their
+// LOW index bits -- and the ranks run the sharded degree-2 prover of sharded.cpp on them (nine sums per exchange, then the table
+// gather).  Every rank absorbs the same bytes and ends with the same proof.  Layers with fewer than two entries per rank run
+// replicated.
+static int gkr_prove_impl(zk_ctx* c, zk_circuit* ci, zk_transcript* tr, const zk_mle* inputs, int world, int rank, int gather_log,
+                          uint64_t* output_poly_out, uint64_t* w_evals_out, uint64_t* claims_out, uint64_t* coeffs_out, double* layer_ms_out) {
     if (!c || !ci || !tr || !inputs || !output_poly_out || !claims_out || !coeffs_out || ci->ctx != c || inputs->ctx != c) return ZK_E_ARG;
     const size_t L = ci->layers.size();
     if (L == 0) return ZK_E_LAYER_OOB; // get_w_i(0) of a lone input layer: prover.rs:38-43 would proceed, but no layer to prove
@@ -284,8 +292,8 @@ int zk_gkr_prove(zk_ctx* c, zk_circuit* ci, zk_transcript* tr, const zk_mle* inp
     }
     const size_t half_tab = (size_t)1 << zkk::kMaxEqVars;
     const size_t eq_half = std::min(half_tab, std::max(max_in, max_out));
-    // scratch: wt[max_out] | Eu[max_in] | A H2 ones T0 T2 T3 [max_in each] | 4 eq half tables
-    const size_t n_elems = max_out + 7 * max_in + 4 * eq_half;
+    // scratch: wt[max_out] | Eu[max_in] | A H2 ones T0 T2 T3 Wl [max_in each] | 4 eq half tables
+    const size_t n_elems = max_out + 8 * max_in + 4 * eq_half;
     if (c->gkr_scratch_cap < n_elems * kElem) { // kept in the context between proofs (a few hundred MiB at 2^20 gates per layer)
         if (c->gkr_scratch) { HIPCHK(c, hipFree(c->gkr_scratch)); c->gkr_scratch = nullptr; c->gkr_scratch_cap = 0; }
         HIPCHK(c, hipMalloc(&c->gkr_scratch, n_elems * kElem));
@@ -296,6 +304,7 @@ int zk_gkr_prove(zk_ctx* c, zk_circuit* ci, zk_transcript* tr, const zk_mle* inp
     void* wt = take(max_out);
     void* Eu = take(max_in);
     void *A = take(max_in), *H2 = take(max_in), *ones = take(max_in), *T0 = take(max_in), *T2 = take(max_in), *T3 = take(max_in);
+    void* Wl = take(max_in); // a rank's shard of the next layer's table (sharded proves)
     void* eqs[4] = {take(eq_half), take(eq_half), take(eq_half), take(eq_half)};
     zkk::launch_fill_one(ones, max_in, c->stream);
 
@@ -375,21 +384,31 @@ int zk_gkr_prove(zk_ctx* c, zk_circuit* ci, zk_transcript* tr, const zk_mle* inp
 
         std::vector<uint64_t> ch(4 * 2 * (size_t)k_in);
         uint64_t fin[16];
+        const bool shard_layer = world > 1 && n_in >= 2 * (size_t)world;
+        const size_t n_loc = shard_layer ? n_in / (size_t)world : n_in, step = shard_layer ? (size_t)world : 1, first = shard_layer ? (size_t)rank : 0;
+        const void* Wt = Wn->d; // the W factor table of both phases: the whole table, or this rank's shard of it
+        if (shard_layer) {
+            zkk::launch_stride_gather(Wl, Wn->d, n_loc, step, first, c->stream);
+            Wt = Wl;
+        }
+        auto prove = [&](const void* const t[4], uint64_t* co, uint64_t* chal) -> int {
+            return shard_layer ? prove_sum2x2_sharded_dev(c, t, n_loc, tr, gather_log, co, chal, fin) : prove_sum2x2_dev(c, t, n_in, tr, co, chal, fin);
+        };
         // rounds over b
-        zkk::launch_gkr_phase1(A, H2, Ly.lptr, Ly.lidx, Ly.right, Ly.op, wt, Wn->d, n_in, c->stream);
+        zkk::launch_gkr_phase1(A, H2, Ly.lptr, Ly.lidx, Ly.right, Ly.op, wt, Wn->d, n_loc, step, first, c->stream);
         HIPCHK(c, hipGetLastError());
         {
-            const void* t[4] = {A, Wn->d, H2, ones};
-            if ((rc = prove_sum2x2_dev(c, t, n_in, tr, coeffs_out + 12 * coeff_off, ch.data(), fin))) return rc;
+            const void* t[4] = {A, Wt, H2, ones};
+            if ((rc = prove(t, coeffs_out + 12 * coeff_off, ch.data()))) return rc;
         }
         const Fq wu = zkh::load(fin + 4); // W_{i+1}(u)
         // rounds over c
         build_eq(c, Eu, k_in, ch.data(), zkh::one(), eqs[0], eqs[1]);
-        zkk::launch_gkr_phase2(T0, T2, T3, Ly.rptr, Ly.ridx, Ly.left, Ly.op, wt, Eu, Wn->d, wu.l, n_in, c->stream);
+        zkk::launch_gkr_phase2(T0, T2, T3, Ly.rptr, Ly.ridx, Ly.left, Ly.op, wt, Eu, Wn->d, wu.l, n_loc, step, first, c->stream);
         HIPCHK(c, hipGetLastError());
         {
-            const void* t[4] = {T0, Wn->d, T2, T3};
-            if ((rc = prove_sum2x2_dev(c, t, n_in, tr, coeffs_out + 12 * (coeff_off + k_in), ch.data() + 4 * k_in, fin))) return rc;
+            const void* t[4] = {T0, Wt, T2, T3};
+            if ((rc = prove(t, coeffs_out + 12 * (coeff_off + k_in), ch.data() + 4 * k_in))) return rc;
         }
         wb = wu;
         wc = zkh::load(fin + 4); // W_{i+1}(v)
@@ -405,6 +424,25 @@ int zk_gkr_prove(zk_ctx* c, zk_circuit* ci, zk_transcript* tr, const zk_mle* inp
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return ZK_OK;
+}
+
+extern "C" {
+
+int zk_gkr_prove(zk_ctx* c, zk_circuit* ci, zk_transcript* tr, const zk_mle* inputs, uint64_t* output_poly_out, uint64_t* w_evals_out,
+                 uint64_t* claims_out, uint64_t* coeffs_out, double* layer_ms_out) {
+    return gkr_prove_impl(c, ci, tr, inputs, 1, 0, 0, output_poly_out, w_evals_out, claims_out, coeffs_out, layer_ms_out);
+}
+
+int zk_gkr_prove_sharded(zk_ctx* c, zk_circuit* ci, zk_transcript* tr, const zk_mle* inputs, int gather_log, uint64_t* output_poly_out,
+                         uint64_t* w_evals_out, uint64_t* claims_out, uint64_t* coeffs_out, double* layer_ms_out) {
+    if (!c) return ZK_E_ARG;
+    if (!c->comm) {
+        c->err = "no communicator on this context (zk_comm_init_rccl / zk_comm_init_host)";
+        return ZK_E_COMM;
+    }
+    if (gather_log < 0) return ZK_E_ARG; // W(u), W(v) come out of the replicated finish of each phase
+    return gkr_prove_impl(c, ci, tr, inputs, zk_comm_world(c), zk_comm_rank(c), gather_log, output_poly_out, w_evals_out, claims_out, coeffs_out,
+                          layer_ms_out);
 }
 
 // ---- GKRVerifier::verify_proof (gkr/src/verifier.rs:21-119) --------------------------------------

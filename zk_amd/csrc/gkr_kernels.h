@@ -23,17 +23,20 @@ void launch_eq_small_multi(int njobs, void* const out[], const int k[], const ui
 void launch_eq_outer(void* out, size_t n, int log_lo, const void* hiA, const void* loA, const void* hiB, const void* loB,
                      hipStream_t st);
 void launch_fill_one(void* out, size_t n, hipStream_t st);
-// phase 1 (the k_in "b" variables): for every b < n_b, over the gates whose LEFT input is b
+// phase 1 (the k_in "b" variables): for b = i * step + first, i < n_loc (step 1, first 0: every b; a rank of a sharded prove takes
+// the b that are `first` mod `step`: tables sharded on their low index bits), over the gates whose LEFT input is b
 // (CSR: gate ids lidx[lptr[b] .. lptr[b+1])):
-//   A[b]  = sum_{mul gates} wt[o] * W[right]  +  sum_{add gates} wt[o]
-//   H2[b] = sum_{add gates} wt[o] * W[right]
+//   A[i]  = sum_{mul gates} wt[o] * W[right]  +  sum_{add gates} wt[o]
+//   H2[i] = sum_{add gates} wt[o] * W[right]
 void launch_gkr_phase1(void* A, void* H2, const uint32_t* lptr, const uint32_t* lidx, const uint32_t* right, const uint8_t* op,
-                       const void* wt, const void* W, size_t n_b, hipStream_t st);
-// phase 2 (the k_in "c" variables), b bound to u: for every c < n_c over the gates whose RIGHT input is c:
-//   T0[c] = wu * sum_{mul gates} wt[o] * Eu[left],  T2[c] = sum_{add gates} wt[o] * Eu[left],  T3[c] = wu + W[c]
+                       const void* wt, const void* W, size_t n_loc, size_t step, size_t first, hipStream_t st);
+// phase 2 (the k_in "c" variables), b bound to u: for c = i * step + first, i < n_loc, over the gates whose RIGHT input is c:
+//   T0[i] = wu * sum_{mul gates} wt[o] * Eu[left],  T2[i] = sum_{add gates} wt[o] * Eu[left],  T3[i] = wu + W[c]
 void launch_gkr_phase2(void* T0, void* T2, void* T3, const uint32_t* rptr, const uint32_t* ridx, const uint32_t* left,
-                       const uint8_t* op, const void* wt, const void* Eu, const void* W, const uint64_t wu[4], size_t n_c,
-                       hipStream_t st);
+                       const uint8_t* op, const void* wt, const void* Eu, const void* W, const uint64_t wu[4], size_t n_loc, size_t step,
+                       size_t first, hipStream_t st);
+// out[i] = in[i * step + first], i < n_loc
+void launch_stride_gather(void* out, const void* in, size_t n_loc, size_t step, size_t first, hipStream_t st);
 // verifier: per-block shares (2 per block: add, mul) of sum_g wt[o_g] eq(u,l_g) eq(v,r_g); returns the block count (<= 1024)
 int launch_gkr_pred_eval(const uint32_t* left, const uint32_t* right, const uint8_t* op, const void* wt, const void* Eu, const void* Ev,
                          size_t n_gates, void* partials, hipStream_t st);

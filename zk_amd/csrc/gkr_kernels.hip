@@ -94,12 +94,15 @@ __global__ void __launch_bounds__(kT) k_fill_one(fq* __restrict__ out, size_t n)
     for (size_t i = (size_t)blockIdx.x * kT + threadIdx.x; i < n; i += stride) fq_store(out + i, one);
 }
 
+// Rows b = i * step + first, i < n_loc (step = 1, first = 0: the whole table; a rank of a sharded prove takes the rows that are
+// `first` mod `step` and stores them at the local index i: the table is sharded on its LOW index bits, as sharded.cpp needs it)
 __global__ void __launch_bounds__(kT) k_gkr_phase1(fq* __restrict__ A, fq* __restrict__ H2, const u32* __restrict__ lptr,
                                                    const u32* __restrict__ lidx, const u32* __restrict__ right,
                                                    const uint8_t* __restrict__ op, const fq* __restrict__ wt, const fq* __restrict__ W,
-                                                   size_t n_b) {
+                                                   size_t n_loc, size_t step, size_t first) {
     const size_t stride = (size_t)gridDim.x * kT;
-    for (size_t b = (size_t)blockIdx.x * kT + threadIdx.x; b < n_b; b += stride) {
+    for (size_t i = (size_t)blockIdx.x * kT + threadIdx.x; i < n_loc; i += stride) {
+        const size_t b = i * step + first;
         fq a = fq_zero(), h2 = fq_zero();
         for (u32 e = lptr[b]; e < lptr[b + 1]; ++e) {
             const u32 g = lidx[e]; // the gate's output index
@@ -108,8 +111,8 @@ __global__ void __launch_bounds__(kT) k_gkr_phase1(fq* __restrict__ A, fq* __res
             if (op[g]) a = fq_add(a, t);
             else { a = fq_add(a, w); h2 = fq_add(h2, t); }
         }
-        fq_store(A + b, a);
-        fq_store(H2 + b, h2);
+        fq_store(A + i, a);
+        fq_store(H2 + i, h2);
     }
 }
 
@@ -117,9 +120,10 @@ __global__ void __launch_bounds__(kT) k_gkr_phase2(fq* __restrict__ T0, fq* __re
                                                    const u32* __restrict__ rptr, const u32* __restrict__ ridx,
                                                    const u32* __restrict__ left, const uint8_t* __restrict__ op,
                                                    const fq* __restrict__ wt, const fq* __restrict__ Eu, const fq* __restrict__ W, fq wu,
-                                                   size_t n_c) {
+                                                   size_t n_loc, size_t step, size_t first) {
     const size_t stride = (size_t)gridDim.x * kT;
-    for (size_t c = (size_t)blockIdx.x * kT + threadIdx.x; c < n_c; c += stride) {
+    for (size_t i = (size_t)blockIdx.x * kT + threadIdx.x; i < n_loc; i += stride) {
+        const size_t c = i * step + first;
         fq m = fq_zero(), ad = fq_zero();
         for (u32 e = rptr[c]; e < rptr[c + 1]; ++e) {
             const u32 g = ridx[e];
@@ -127,10 +131,16 @@ __global__ void __launch_bounds__(kT) k_gkr_phase2(fq* __restrict__ T0, fq* __re
             if (op[g]) m = fq_add(m, t);
             else ad = fq_add(ad, t);
         }
-        fq_store(T0 + c, fq_mul(m, wu));
-        fq_store(T2 + c, ad);
-        fq_store(T3 + c, fq_add(wu, fq_load(W + c)));
+        fq_store(T0 + i, fq_mul(m, wu));
+        fq_store(T2 + i, ad);
+        fq_store(T3 + i, fq_add(wu, fq_load(W + c)));
     }
+}
+
+// out[i] = in[i * step + first], i < n_loc: a rank's shard of a replicated table
+__global__ void __launch_bounds__(kT) k_stride_gather(fq* __restrict__ out, const fq* __restrict__ in, size_t n_loc, size_t step, size_t first) {
+    const size_t stride = (size_t)gridDim.x * kT;
+    for (size_t i = (size_t)blockIdx.x * kT + threadIdx.x; i < n_loc; i += stride) fq_store(out + i, fq_load(in + i * step + first));
 }
 
 // verifier side: add'(u,v) and mul'(u,v) from the gate list, sum_g wt[o_g] * eq(u, l_g) * eq(v, r_g) split by gate type
@@ -218,14 +228,18 @@ void launch_eq_outer(void* out, size_t n, int log_lo, const void* hiA, const voi
 }
 void launch_fill_one(void* out, size_t n, hipStream_t st) { hipLaunchKernelGGL(k_fill_one, dim3(grid1d(n)), dim3(kT), 0, st, (fq*)out, n); }
 void launch_gkr_phase1(void* A, void* H2, const uint32_t* lptr, const uint32_t* lidx, const uint32_t* right, const uint8_t* op,
-                       const void* wt, const void* W, size_t n_b, hipStream_t st) {
-    hipLaunchKernelGGL(k_gkr_phase1, dim3(grid1d(n_b)), dim3(kT), 0, st, (fq*)A, (fq*)H2, lptr, lidx, right, op, (const fq*)wt, (const fq*)W,
-                       n_b);
+                       const void* wt, const void* W, size_t n_loc, size_t step, size_t first, hipStream_t st) {
+    hipLaunchKernelGGL(k_gkr_phase1, dim3(grid1d(n_loc)), dim3(kT), 0, st, (fq*)A, (fq*)H2, lptr, lidx, right, op, (const fq*)wt, (const fq*)W,
+                       n_loc, step, first);
 }
 void launch_gkr_phase2(void* T0, void* T2, void* T3, const uint32_t* rptr, const uint32_t* ridx, const uint32_t* left, const uint8_t* op,
-                       const void* wt, const void* Eu, const void* W, const uint64_t wu[4], size_t n_c, hipStream_t st) {
-    hipLaunchKernelGGL(k_gkr_phase2, dim3(grid1d(n_c)), dim3(kT), 0, st, (fq*)T0, (fq*)T2, (fq*)T3, rptr, ridx, left, op, (const fq*)wt,
-                       (const fq*)Eu, (const fq*)W, to_fq4(wu), n_c);
+                       const void* wt, const void* Eu, const void* W, const uint64_t wu[4], size_t n_loc, size_t step, size_t first,
+                       hipStream_t st) {
+    hipLaunchKernelGGL(k_gkr_phase2, dim3(grid1d(n_loc)), dim3(kT), 0, st, (fq*)T0, (fq*)T2, (fq*)T3, rptr, ridx, left, op, (const fq*)wt,
+                       (const fq*)Eu, (const fq*)W, to_fq4(wu), n_loc, step, first);
+}
+void launch_stride_gather(void* out, const void* in, size_t n_loc, size_t step, size_t first, hipStream_t st) {
+    hipLaunchKernelGGL(k_stride_gather, dim3(grid1d(n_loc)), dim3(kT), 0, st, (fq*)out, (const fq*)in, n_loc, step, first);
 }
 int launch_gkr_pred_eval(const uint32_t* left, const uint32_t* right, const uint8_t* op, const void* wt, const void* Eu, const void* Ev,
                          size_t n_gates, void* partials, hipStream_t st) {

@@ -336,12 +336,23 @@ int zk_sumcheck_prove_sum2x2_sharded(zk_ctx* c, zk_mle* const tables[4], const u
         if (!tables[t] || tables[t]->ctx != c) return ZK_E_ARG;
     for (int t = 1; t < 4; ++t)
         if (tables[t]->len != tables[0]->len) return ZK_E_LEN_MISMATCH;
+    const void* t[4] = {tables[0]->d, tables[1]->d, tables[2]->d, tables[3]->d};
+    return prove_sum2x2_sharded_dev(c, t, tables[0]->len, tr, gather_log, coeffs_out, challenges_out, nullptr);
+}
+
+} // extern "C"
+
+// the same on raw device tables (the GKR layer prover's); final_out (optional, 4 elements: every table folded at all challenges)
+// needs the table gather (gather_log >= 0)
+int zki::prove_sum2x2_sharded_dev(zk_ctx* c, const void* const tabs[4], size_t len_local, zk_transcript* tr, int gather_log, uint64_t* coeffs_out,
+                                  uint64_t* challenges_out, uint64_t* final_out) {
     if (!c->comm) return comm_fail(c, "no communicator on this context (zk_comm_init_rccl / zk_comm_init_host)");
+    if (final_out && gather_log < 0) return ZK_E_ARG;
     zk_comm* k = c->comm;
     int rc = set_device(c);
     if (rc) return rc;
     const unsigned g = ilog2((size_t)k->world);
-    zk_shard4 s{c, {tables[0]->d, tables[1]->d, tables[2]->d, tables[3]->d}, tables[0]->len, 0};
+    zk_shard4 s{c, {tabs[0], tabs[1], tabs[2], tabs[3]}, len_local, 0};
     unsigned ell = ilog2(s.len), done = 0;
     uint64_t rs[8];
 
@@ -369,7 +380,7 @@ int zk_sumcheck_prove_sum2x2_sharded(zk_ctx* c, zk_mle* const tables[4], const u
             if ((rc = gather_tables(c, k->send_dev, 4, s.len, &all))) return rc;
         const size_t len = s.len * (size_t)k->world;
         for (int t = 0; t < 4; ++t) cur[t] = (const uint8_t*)all + (size_t)t * len * kElem;
-        rc = prove_sum2x2_dev(c, cur, len, tr, coeffs_out + 12 * done, challenges_out ? challenges_out + 4 * done : nullptr, nullptr);
+        rc = prove_sum2x2_dev(c, cur, len, tr, coeffs_out + 12 * done, challenges_out ? challenges_out + 4 * done : nullptr, final_out);
         prof_collect(c);
         return rc;
     }
@@ -401,5 +412,3 @@ int zk_sumcheck_prove_sum2x2_sharded(zk_ctx* c, zk_mle* const tables[4], const u
     prof_collect(c);
     return ZK_OK;
 }
-
-} // extern "C"

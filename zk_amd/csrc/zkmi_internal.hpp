@@ -285,6 +285,9 @@ int prove_mle_dev(zk_ctx* c, const void* table, unsigned n, zk_transcript* tr, u
                   uint64_t* challenges_out);
 int prove_sum2x2_dev(zk_ctx* c, const void* const tables[4], size_t len, zk_transcript* tr, uint64_t* coeffs_out,
                      uint64_t* challenges_out, uint64_t* final_out);
+// defined in sharded.cpp: the same for tables sharded over the ranks of the context's communicator (len_local entries per rank)
+int prove_sum2x2_sharded_dev(zk_ctx* c, const void* const tabs[4], size_t len_local, zk_transcript* tr, int gather_log, uint64_t* coeffs_out,
+                             uint64_t* challenges_out, uint64_t* final_out);
 
 } // namespace zki
 using namespace zki;

@@ -45,7 +45,9 @@ def _limbs_le32(limbs: np.ndarray, ctx) -> bytes:
 
 class GKRProver:
     @staticmethod
-    def generate_proof(circuit: Circuit, transcript: Transcript, inputs, timing: bool = False) -> GKRProof:
+    def generate_proof(circuit: Circuit, transcript: Transcript, inputs, timing: bool = False, sharded_gather_log: int | None = None) -> GKRProof:
+        """sharded_gather_log: None = this GPU alone (zk_gkr_prove); an integer = this process is a rank of the context's
+        communicator (zk_amd.sharded.comm_init) and every layer's sumcheck is sharded over the ranks (zk_gkr_prove_sharded)."""
         ctx = circuit.ctx
         if not isinstance(inputs, MultiLinearPolynomial):
             inputs = MultiLinearPolynomial(inputs, ctx=ctx)
@@ -56,9 +58,14 @@ class GKRProver:
         claims = np.empty((n_layers, 4), dtype=np.uint64)
         coeffs = np.empty((max(sum(rounds), 1), 3, 4), dtype=np.uint64)
         ms = (C.c_double * (n_layers + 2))()
-        check(lib().zk_gkr_prove(ctx.h, circuit.h, transcript.h, inputs.h, output.ctypes.data_as(u64p),
-                                 w_evals.ctypes.data_as(u64p), claims.ctypes.data_as(u64p), coeffs.ctypes.data_as(u64p),
-                                 ms if timing else None), ctx.h)
+        if sharded_gather_log is None:
+            check(lib().zk_gkr_prove(ctx.h, circuit.h, transcript.h, inputs.h, output.ctypes.data_as(u64p),
+                                     w_evals.ctypes.data_as(u64p), claims.ctypes.data_as(u64p), coeffs.ctypes.data_as(u64p),
+                                     ms if timing else None), ctx.h)
+        else:
+            check(lib().zk_gkr_prove_sharded(ctx.h, circuit.h, transcript.h, inputs.h, int(sharded_gather_log), output.ctypes.data_as(u64p),
+                                             w_evals.ctypes.data_as(u64p), claims.ctypes.data_as(u64p), coeffs.ctypes.data_as(u64p),
+                                             ms if timing else None), ctx.h)
         proofs, off = [], 0
         for i, r in enumerate(rounds):
             proofs.append(SumCheckProof(claims[i].copy(), coeffs[off:off + r].copy()))
