@@ -6,9 +6,11 @@
 // j with entry j + N/2 (prover.rs:29-41): two contiguous streams, one 32-byte element per lane,
 // two global_load_dwordx4 each.
 //
-// All kernels are HBM-streaming integer kernels: no LDS tiling (no reuse), no MFMA.  Grids are
-// capped at kMaxBlocks x 256 threads and grid-stride, block -> per-block partial sums, one
-// small second-stage kernel folds the partials (fixed order: results are bit-reproducible).
+// The big passes are HBM-streaming integer kernels: every byte is read once per pass, so there is nothing to tile for reuse.  LDS
+// is the landing zone of the LDS-DMA streams (per-wave rings) and of the byte-transposed operand reads; the matrix cores are used
+// where a pass is a dense contraction once its operands are cut into bytes (k_multifold_wide_mfma, k_sum16_mfma, k_cross64_mfma).
+// Grids are capped and grid-stride, block -> per-block partial sums, one small second-stage kernel folds the partials (field
+// addition is exact: results are bit-reproducible whatever the order).
 #include <algorithm>
 #include <cstdlib>
 #include <mutex>
