@@ -212,3 +212,23 @@ def test_constant_tables_of_p_minus_1_worst_case_limbs():
     for other in proofs[1:]:
         assert np.array_equal(proofs[0][0], other[0]) and np.array_equal(proofs[0][1], other[1])
     ctx.close()
+
+
+def test_sum2x2_zero_tables_at_the_accumulator_bound():
+    """All-zero tables put every signed byte product of the matrix-core sweeps at its maximum (+2^14, from (0 - 128)^2) and 4 x 2^26
+    entries give every workgroup of k_cross64_mfma its largest share (2^16 quarter-indices): the i32 accumulators end at 2^30.
+    The proof of the zero polynomial is all zeros and verifies."""
+    ctx = zk_amd.Context(0)
+    n = 1 << 26
+    z = np.zeros((n, 4), dtype=np.uint64)
+    tabs = [MLE(z, ctx=ctx) for _ in range(4)]
+    del z
+    f = zk_amd.SumPolynomial([zk_amd.ProductPolynomial(tabs[:2]), zk_amd.ProductPolynomial(tabs[2:])])
+    ctx.forms_used()
+    proof, pts = zk_amd.SumcheckProver.generate_proof_for_partial_verify(O.fq1(0), f, zk_amd.Transcript())
+    assert "cross64" in ctx.forms_used()
+    assert proof.round_polys.shape == (26, 3, 4) and not proof.round_polys.any()
+    ok, final, ch = zk_amd.SumcheckVerifier.partial_verify(proof, zk_amd.Transcript())
+    assert ok and np.array_equal(ch, pts) and not np.asarray(final).any()
+    del tabs, f
+    ctx.close()

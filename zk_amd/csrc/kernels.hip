@@ -1863,14 +1863,16 @@ void launch_sum9(const void* const t[4], size_t q, const uint64_t fix24[4], int 
     else hipLaunchKernelGGL((k_sum9<false>), dim3((unsigned)gx, 2), dim3(kThreads), 0, st, T, q, (fq*)partials);
     hipLaunchKernelGGL(k_reduce9, dim3(9), dim3(kThreads), 0, st, (const fq*)partials, (int)gx, ysplit ? 1 : 0, (fq*)out);
 }
-bool cross64_fits(size_t q) { return q >= 64 && q % 64 == 0 && q <= ((size_t)kMaxBlocks9 << 17); }
+// a workgroup's i32 accumulators take 2^16 quarter-indices: |byte - 128| <= 128, so a product is <= 2^14 and 2^16 of them stay below
+// 2^31 with a factor of two to spare (2^17 all-zero entries would reach exactly 2^31)
+bool cross64_fits(size_t q) { return q >= 64 && q % 64 == 0 && q <= ((size_t)kMaxBlocks9 << 16); }
 void launch_cross64(const void* const t[4], size_t q, int ring, void* partials, void* out, hipStream_t st) {
     Tab4 T;
     for (int k = 0; k < 4; ++k) T.t[k] = (const fq*)t[k];
     // one workgroup per CU and term half: 128 x 2 persistent workgroups; more only to keep a workgroup's share within the i32
-    // accumulators (2^17 quarter-indices)
+    // accumulators (2^16 quarter-indices)
     size_t gx = std::min<size_t>(q / 64, 128);
-    const size_t need = (q + ((size_t)1 << 17) - 1) >> 17;
+    const size_t need = (q + ((size_t)1 << 16) - 1) >> 16;
     if (gx < need) gx = need;
     fq* red = (fq*)partials + 2 * gx * 80; // 160 reduced values behind the partials (kSum9PartialElems)
     fq qn{};
