@@ -63,6 +63,7 @@ def parse(argv=None):
     ap.add_argument("--deg2-mfma-from", type=int, default=None, help="degree-2 prover: nine sums on the matrix cores from 2^k quarter-entries (64 = never)")
     ap.add_argument("--deg2-triple-from", type=int, default=None, help="degree-2 prover: three rounds per pass on tables of >= 2^k entries (64 = never)")
     ap.add_argument("--deg2-fused-below", type=int, default=None, help="degree-2 prover: fold + nine sums in one kernel for folded tables below 2^k entries (0 = never)")
+    ap.add_argument("--deg2-fold3-fused", type=int, default=None, help="degree-2 prover: three-variable fold fused with the next cross sums (0 = off, 4..6 = DMA slots per wave)")
     ap.add_argument("--deg2-triple-ring", type=int, default=3, help="LDS tiles of the three-round sweep (3 or 4)")
     ap.add_argument("--weak", action="store_true", help="multi-GPU: 2^log_n entries PER GPU instead of in total")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend of the ranks' rendezvous (nccl = RCCL; gloo for rehearsals)")
@@ -264,6 +265,8 @@ def apply_knobs(args, ctx):
         ctx.set_deg2_lazy_sums(args.deg2_lazy_from)
     if args.deg2_mfma_from is not None:
         ctx.set_deg2_mfma_sums(args.deg2_mfma_from)
+    if args.deg2_fold3_fused is not None:
+        ctx.set_deg2_fold3_fused(args.deg2_fold3_fused)
     if args.deg2_fused_below is not None:
         ctx.set_deg2_fused(args.deg2_fused_below)
     if args.deg2_triple_from is not None:

@@ -373,7 +373,7 @@ int zk_ctx_set_wide_mfma(zk_ctx *ctx, int from_log, int workgroups_per_cu, int d
 enum { ZK_FORM_SUMS_DMA = 1 << 0, ZK_FORM_SUMS_REG = 1 << 1, ZK_FORM_WIDE_DMA = 1 << 2, ZK_FORM_WIDE_DMA_STREAM = 1 << 3,
        ZK_FORM_WIDE_REG = 1 << 4, ZK_FORM_WIDE_LDS = 1 << 5, ZK_FORM_COOP = 1 << 6, ZK_FORM_FOLD2_DMA = 1 << 7,
        ZK_FORM_FOLD2_REG = 1 << 8, ZK_FORM_SUM9_LAZY = 1 << 9, ZK_FORM_SUM9 = 1 << 10, ZK_FORM_FOLD2_SUM9 = 1 << 11, ZK_FORM_WIDE_MFMA = 1 << 12, ZK_FORM_SUM9_MFMA = 1 << 13,
-       ZK_FORM_CROSS64 = 1 << 14, ZK_FORM_FOLD3_DMA = 1 << 15 };
+       ZK_FORM_CROSS64 = 1 << 14, ZK_FORM_FOLD3_DMA = 1 << 15, ZK_FORM_FOLD3_CROSS64 = 1 << 16 };
 unsigned zk_ctx_forms_used(zk_ctx *ctx, int reset);
 /* Nine-sum sweeps over tables of at least 2^from_log quarter-entries (64 = never) run on the matrix cores: the sixteen cross sums
  * of a term's entries as 32 x 32 byte-product matrices (v_mfma_i32_32x32x32_i8 with the contraction over the quarter-index,
@@ -384,6 +384,10 @@ int zk_ctx_set_deg2_mfma_sums(zk_ctx *ctx, int from_log);
  * sum_j F_e[j] G_e'[j] of both terms on the matrix cores, the host runs three rounds on them, one fold binds the three variables.
  * ring = 3 or 4 LDS tiles in the sweep.  An execution schedule: proof bytes do not depend on it. */
 int zk_ctx_set_deg2_triple(zk_ctx *ctx, int from_log, int ring);
+/* Three-round passes whose successor serves three rounds too: the three-variable fold and the next level's cross sums are ONE sweep
+ * (k_fold3_cross64: the folded rows go to HBM and into the LDS tile of the matrix stage, so the folded tables are not re-read).
+ * dma_slots = LDS-DMA slots per wave, 3..5; 0 = separate fold and sums sweeps.  Proof bytes do not depend on it. */
+int zk_ctx_set_deg2_fold3_fused(zk_ctx *ctx, int dma_slots);
 /* Degree-2 prover, two rounds per pass: while the folded tables have fewer than 2^below_log entries (0 = never) the two-variable fold
  * (prover.rs:131-139, twice) and the nine sums of its result (the next two rounds' prover.rs:89-107) are one kernel -- GKR layer
  * tables are cache-resident and a pass is bound by launches and per-lane chains, not by bytes.  Proof bytes do not depend on it. */

@@ -1,20 +1,11 @@
 set -o pipefail
-B="python -u bench.py --no-extra --no-absorb --no-cpu-baseline --steps 10 --warmup 3"
-run() {
-  echo "== $*"
-  timeout -k 10 120 env "$@" $B 2>/dev/null | python3 -c "
+B="python -u bench.py --workload sum2x2 --no-extra --no-cpu-baseline --steps 5 --warmup 2"
+for n in 22 23 24 25; do
+for cfg in "--deg2-fold3-fused 0" "--deg2-fold3-fused 4" "--deg2-fold3-fused 0 --deg2-triple-from 18" "--deg2-fold3-fused 4 --deg2-triple-from 18"; do
+  echo "== 4x2^$n $cfg"
+  timeout -k 10 120 $B --log-n $n $cfg 2>/dev/null | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read())
-print('prove_ms', round(d['ms_per_step'],4), {k:(round(v['avg_ms'],4), round(v['achieved_GBs'],0)) for k,v in d['kernels'].items() if v['launches']})
+print('prove_ms', round(d['ms_per_step'],4), {k:(v['launches'], round(v['total_ms']/5,4), round(v['achieved_GBs'],0)) for k,v in d['kernels'].items()})
 " || exit 1
-}
-run ZK_BS_ROT=0
-run ZK_BS_ROT=64
-run ZK_BS_ROT=67
-run ZK_BS_ROT=1
-run ZK_BS_ROT=8
-run ZK_BS_ROT=0 ZK_BS_GPB=4
-run ZK_BS_ROT=64 ZK_BS_GPB=4
-run ZK_BS_ROT=0 ZK_BS_GPB=16
-run ZK_BS_ROT=64 ZK_BS_GPB=16
-run ZK_BS_ROT=16 ZK_BS_GPB=16
+done; done

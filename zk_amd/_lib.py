@@ -116,6 +116,7 @@ SYMBOLS = [
     ("zk_ctx_set_deg2_mfma_sums", C.c_int, [_VP, C.c_int]),
     ("zk_ctx_set_deg2_triple", C.c_int, [_VP, C.c_int, C.c_int]),
     ("zk_ctx_set_deg2_fused", C.c_int, [_VP, C.c_int]),
+    ("zk_ctx_set_deg2_fold3_fused", C.c_int, [_VP, C.c_int]),
     ("zk_ctx_set_validate", C.c_int, [_VP, C.c_int]),
     ("zk_mle_count_noncanonical", C.c_int, [_VP, C.POINTER(C.c_uint64)]),
     ("zk_ctx_set_gkr_strict_claims", C.c_int, [_VP, C.c_int]),

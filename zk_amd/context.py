@@ -9,7 +9,7 @@ KERNELS = {"block_sums": 0, "multifold": 1, "fold": 2, "eval3": 3, "fold4_eval3"
 
 
 FORMS = ["sums_dma", "sums_reg", "wide_dma", "wide_dma_stream", "wide_reg", "wide_lds", "coop", "fold2_dma", "fold2_reg", "sum9_lazy", "sum9",
-         "fold2_sum9", "wide_mfma", "sum9_mfma", "cross64", "fold3_dma"]
+         "fold2_sum9", "wide_mfma", "sum9_mfma", "cross64", "fold3_dma", "fold3_cross64"]
 
 
 class Context:
@@ -72,6 +72,10 @@ class Context:
     def set_deg2_mfma_sums(self, from_log: int = 16):
         """Degree-2 prover: nine-sum sweeps over >= 2^from_log quarter-entries run on the matrix cores (64 = never)."""
         check(lib().zk_ctx_set_deg2_mfma_sums(self.h, from_log))
+
+    def set_deg2_fold3_fused(self, dma_slots: int = 4):
+        """Degree-2 prover, three-round passes followed by another: fold and the next cross sums in one sweep (0 = off; 4..6 = DMA slots per wave)."""
+        check(lib().zk_ctx_set_deg2_fold3_fused(self.h, dma_slots))
 
     def set_deg2_fused(self, below_log: int = 20):
         """Degree-2 prover: fold + nine sums of the result in one kernel while the folded tables have < 2^below_log entries (0 = never)."""

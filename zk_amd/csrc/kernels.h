@@ -36,6 +36,7 @@ enum Form : unsigned {
     kFormSum9Mfma = 1u << 13,     // k_sum16_mfma (the nine sums on the matrix cores)
     kFormCross64 = 1u << 14,      // k_cross64_mfma (three rounds per pass: 8 x 8 cross sums per term on the matrix cores)
     kFormFold3Dma = 1u << 15,     // m = 3 LDS-DMA fold of the degree-2 branch (three rounds per pass)
+    kFormFold3Cross64 = 1u << 16, // k_fold3_cross64 (that fold fused with the next level's cross sums)
 };
 extern thread_local unsigned g_forms;
 // Size thresholds of the LDS-DMA forms (log2 of entries; defaults = the measured break-even points)
@@ -49,6 +50,7 @@ struct DmaGates {
     int wide_mfma_depth = 2;       // its pipeline depth K (2..4): table rows of K steps in flight per wave
     int deg2_triple_from_log = 21; // degree-2 prover: three rounds per pass (k_cross64_mfma + m = 3 fold) on tables of >= 2^k entries; 64 = never
     int deg2_fused_below_log = 20; // degree-2 prover: fold + nine sums in one kernel (k_fold2_sum9) for folded tables below 2^k entries; 0 = never
+    int deg2_fold3_fused = 4;      // three-round passes: fold fused with the next level's cross sums (k_fold3_cross64); value = DMA slots per wave (3..5), 0 = off
     int deg2_triple_ring = 4;      // its LDS ring: 3 or 4 tiles of 32 KiB
 };
 // out[b] (b < 2^log_ob) = sum of the b-th contiguous block of T (L entries); partials is scratch
@@ -101,6 +103,10 @@ void launch_fold3_tables(const void* const s[4], void* const d[4], size_t outlen
                          void* partials, hipStream_t st, const DmaGates& gates = DmaGates());
 // launch_fold2_tables followed by launch_sum9 on its result, as one kernel + the second stage (small, cache-resident tables; outlen >= 4)
 void launch_fold2_sum9(const void* const s[4], void* const d[4], size_t outlen, const uint32_t* w28, void* partials, void* out, hipStream_t st);
+// launch_fold3_tables followed by launch_cross64 on d[], in one sweep: the folded tables are not re-read (needs cross64_fits(outlen / 8));
+// ring = LDS-DMA slots per wave (3, 4 or 5)
+void launch_fold3_cross64(const void* const s[4], void* const d[4], size_t outlen, const uint64_t* r3, const uint64_t two24[4], void* wbuf,
+                          int ring, void* partials, void* out, hipStream_t st, const DmaGates& gates = DmaGates());
 // out[k*n + i] = t[k][i], k < 4, i < n
 void launch_gather4(const void* const t[4], size_t n, void* out, hipStream_t st);
 // out[(t * L + j) * world + q] = in[(q * ntab + t) * L + j]: the ranks' gathered local tables (rank-major) -> the remaining

@@ -1377,6 +1377,181 @@ __global__ void __launch_bounds__(512) k_cross64_mfma(Tab4 T, size_t q, fq* __re
         fq_store(out + NE * NE + NE + w, bsum);
     }
 }
+// ---- the three-variable fold FUSED with the next level's cross sums -----------------------------------------------------------------
+// A three-round pass is fold (read 8 entries, write 1) + cross sums of the result (read it again).  Here the fold's outputs go to
+// HBM AND into the LDS tile the matrix stage reads, so the folded tables are not re-read: per prove the tables move 1 + 9/7 = 2.29
+// times instead of 2.43.  A workgroup = 8 waves on one term; per tile of 64 next-level eighth-indices j'' wave w folds the two
+// tile rows r = 2w, 2w + 1 (row r = entry e'' = r & 7 of factor r >> 3: dst[e'' q'' + j''] = sum_b W_b src[b outlen + e'' q'' + j'']),
+// each from eight source rows streamed through the wave's own LDS-DMA ring (D slots of 2 KiB, D - 1 in flight, counted vmcnt: the
+// stream runs on across tiles and under the matrix stage), stores them, writes them into tile buffer t & 1 and adds them to its two
+// plain sums; one s_barrier per tile; then the matrix stage of k_cross64_mfma on the tile (wave w: C[w][0..7]).  Two tile buffers:
+// a wave passes barrier t + 1 only after its matrix stage t, so buffer t & 1 is free when tile t + 2 is written.
+// wts: the eight weights eq((r0,r1,r2), b) * 2^280 as 10 x 28-bit limbs each (k_eq_weights28), scalar loads.
+// partials as k_cross64_mfma: [(term * gridDim.x + bx) * 80 + ...], plain sums at 64 + r.
+template <bool BIG, int D>
+__global__ void __launch_bounds__(512) k_fold3_cross64(Tab4 S, Tab4w Dst, size_t outlen, const u32* __restrict__ wts, fq* __restrict__ partials) {
+    constexpr int NE = 8;
+    __shared__ u32x4 tile[2 * NE][128];  // ONE tile buffer: a second barrier per tile guards its reuse (see below)
+    __shared__ u32x4 ring[8][D][128];
+    __shared__ u32 pl[8][2][9][64];      // per lane: plain sums of the folded rows 2w and 2w + 1 (kept out of the registers)
+    const int term = blockIdx.y, lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const size_t qn = outlen >> 3; // the next level's eighth
+    const size_t stride = (size_t)gridDim.x * 64, base0 = (size_t)blockIdx.x * 64;
+    const int nt = base0 < qn ? (int)((qn - base0 + stride - 1) / stride) : 0;
+    const int nsteps = nt * 16; // source rows of this wave: step s = 16 t + 8 rr + b
+    // rows 2w, 2w + 1 belong to the same factor table (w < 4: F, else G)
+    const fq* __restrict__ src = S.t[2 * term + (w >> 2)];
+    fq* __restrict__ dst = Dst.t[2 * term + (w >> 2)];
+    const size_t e0 = (size_t)((2 * w) & 7); // entry of row 2w; row 2w + 1: e0 + 1
+    auto issue = [&](int s) {
+        const int t = s >> 4, rr = (s >> 3) & 1, b = s & 7;
+        const fq* p0 = src + (size_t)b * outlen + (e0 + (size_t)rr) * qn + base0 + (size_t)t * stride;
+        const u32x4* p = reinterpret_cast<const u32x4*>(p0) + lane;
+        const int slot = s % D;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
+                                         (__attribute__((address_space(3))) void*)&ring[w][slot][0], 16, 0, 2);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p + 64),
+                                         (__attribute__((address_space(3))) void*)&ring[w][slot][64], 16, 0, 2);
+    };
+    v16i acc[NE];
+#pragma unroll
+    for (int e = 0; e < NE; ++e)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc[e][k] = 0;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) pl[w][0][k][lane] = pl[w][1][k][lane] = 0;
+    const int gg = lane >> 4, qq = (lane >> 1) & 7, pp = lane & 1; // transposed-read address inside a row: see k_sum16_mfma
+    const u32 tr_off = (u32)((16 * (gg >> 1) + qq) * 32 + 16 * (gg & 1) + 8 * pp);
+#pragma unroll
+    for (int s = 0; s < D; ++s)
+        if (s < nsteps) issue(s);
+    for (int t = 0; t < nt; ++t) {
+#pragma nounroll
+        for (int rr = 0; rr < 2; ++rr) {
+            u64 a28[20];
+#pragma unroll
+            for (int k = 0; k < 20; ++k) a28[k] = 0;
+            // rolled: one source row at a time (an unrolled loop keeps sixteen row addresses and interleaved rows alive in registers
+            // this kernel does not have)
+#pragma nounroll
+            for (int b = 0; b < 8; ++b) {
+                const int s = 16 * t + 8 * rr + b;
+                // younger than row s when it is waited for: rows s+1 .. s+D-1 (two instructions each) and, for b < D, the two store
+                // instructions of the previous output row (none before the first); the last D rows of a wave drain
+                if (s + D <= nsteps) {
+                    if (b < D && s >= 8) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (D - 1) + 2) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (D - 1)) : "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                const int slot = s % D;
+                const u32x4 lo = ring[w][slot][2 * lane], hi = ring[w][slot][2 * lane + 1];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // in registers before the slot is refilled
+                if (s + D < nsteps) issue(s + D);
+                fq x;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { x.v[k] = lo[k]; x.v[4 + k] = hi[k]; }
+                fq28_mac(a28, x, wts + 10 * b);
+            }
+            const fq o = fq28_redc(a28);
+            fq* out = dst + (e0 + (size_t)rr) * qn + base0 + (size_t)t * stride + lane;
+            if (BIG) fq_store_stream(out, o); else fq_store(out, o);
+            if (rr == 0 && t > 0) { // every wave has finished the matrix stage of tile t - 1: the tile buffer is free
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+            }
+            tile[2 * w + rr][2 * lane] = u32x4{o.v[0], o.v[1], o.v[2], o.v[3]};
+            tile[2 * w + rr][2 * lane + 1] = u32x4{o.v[4], o.v[5], o.v[6], o.v[7]};
+            u32 c = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const u32 v = __builtin_addc(pl[w][rr][k][lane], o.v[k], c, &c);
+                pl[w][rr][k][lane] = v;
+            }
+            pl[w][rr][8][lane] += c;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // this wave's two tile rows are written
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const u32 tb = (u32)(uintptr_t)&tile[0][0];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) { // 32 eighth-indices per step; the G rows in two halves (the operands of four products at a time)
+            const u32 a0 = tb + (u32)w * 2048u + (u32)ks * 1024u + tr_off;  // row F_w
+            u64 fa0, fa1;
+            asm volatile("ds_read_b64_tr_b8 %0, %2\n\tds_read_b64_tr_b8 %1, %2 offset:256" : "=&v"(fa0), "=&v"(fa1) : "v"(a0) : "memory");
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const u32 b0 = tb + (u32)(NE + 4 * h) * 2048u + (u32)ks * 1024u + tr_off; // rows G_4h .. G_4h+3
+                u64 gb[4][2];
+                asm volatile(
+                    "ds_read_b64_tr_b8 %0, %10\n\t"
+                    "ds_read_b64_tr_b8 %1, %10 offset:256\n\t"
+                    "ds_read_b64_tr_b8 %2, %10 offset:2048\n\t"
+                    "ds_read_b64_tr_b8 %3, %10 offset:2304\n\t"
+                    "ds_read_b64_tr_b8 %4, %10 offset:4096\n\t"
+                    "ds_read_b64_tr_b8 %5, %10 offset:4352\n\t"
+                    "ds_read_b64_tr_b8 %6, %10 offset:6144\n\t"
+                    "ds_read_b64_tr_b8 %7, %10 offset:6400\n\t"
+                    "s_waitcnt lgkmcnt(0)"
+                    : "=&v"(gb[0][0]), "=&v"(gb[0][1]), "=&v"(gb[1][0]), "=&v"(gb[1][1]), "=&v"(gb[2][0]), "=&v"(gb[2][1]), "=&v"(gb[3][0]),
+                      "=&v"(gb[3][1]), "+v"(fa0), "+v"(fa1)
+                    : "v"(b0)
+                    : "memory");
+                const u64 sx = 0x8080808080808080ull;
+                const u64 f0 = fa0 ^ sx, f1 = fa1 ^ sx;
+                const v4i A = v4i{(int)(u32)f0, (int)(u32)(f0 >> 32), (int)(u32)f1, (int)(u32)(f1 >> 32)};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const u64 x0 = gb[e][0] ^ sx, x1 = gb[e][1] ^ sx;
+                    const v4i B = v4i{(int)(u32)x0, (int)(u32)(x0 >> 32), (int)(u32)x1, (int)(u32)(x1 >> 32)};
+                    acc[4 * h + e] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, B, acc[4 * h + e], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // ---- epilogue: once per wave (as k_cross64_mfma)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads(); // every wave is done with the tiles: they become scratch (4 KiB per wave)
+    int* mat = reinterpret_cast<int*>(&tile[0][0]) + w * 1024;
+    const fq r2 = {FQ_R2_LIMBS};
+    fq* out = partials + ((size_t)term * gridDim.x + blockIdx.x) * (NE * NE + 2 * NE);
+    fq wk;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) wk.v[k] = kPow256ModP[lane < 63 ? lane : 0][k];
+    for (int e = 0; e < NE; ++e) { // rolled: the body is large and runs once
+        v16i a = acc[0];
+#pragma unroll
+        for (int e2 = 1; e2 < NE; ++e2)
+            if (e == e2) a = acc[e2];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) mat[((k & 3) + 8 * (k >> 2) + 4 * (lane >> 5)) * 32 + (lane & 31)] = a[k];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        long long d = 0;
+        const int klo = lane > 31 ? lane - 31 : 0, khi = lane < 31 ? lane : 31;
+        for (int i = klo; i <= khi && lane < 63; ++i) d += mat[i * 32 + (lane - i)];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const bool neg = d < 0;
+        const unsigned long long ad = (unsigned long long)(neg ? -d : d);
+        fq x = fq_zero();
+        x.v[0] = (u32)ad;
+        x.v[1] = (u32)(ad >> 32);
+        fq prod = fq_mul(x, wk);
+        if (neg) prod = fq_sub(fq_zero(), prod);
+        const fq mine = fq_wave_sum(prod);
+        if (lane == 0) fq_store(out + NE * w + e, mine);
+    }
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+        fq lo, hi = fq_zero();
+#pragma unroll
+        for (int k = 0; k < 8; ++k) lo.v[k] = pl[w][rr][k][lane];
+        hi.v[0] = pl[w][rr][8][lane];
+        const fq sum = fq_wave_sum(fq_add(fq_reduce_256(lo), fq_mul(hi, r2)));
+        if (lane == 0) fq_store(out + NE * NE + 2 * w + rr, sum); // rows 0..7 = A_e, rows 8..15 = B_e'
+    }
+}
+
 // second stage: one block per (term, value): red[term * nv + v] = sum over the workgroups (fixed order)
 __global__ void __launch_bounds__(kThreads) k_reduce_cross(const fq* __restrict__ partials, int gx, int nv, fq* __restrict__ red) {
     const int term = blockIdx.x / nv, v = blockIdx.x % nv;
@@ -1881,6 +2056,33 @@ void launch_cross64(const void* const t[4], size_t q, int ring, void* partials, 
     g_forms |= kFormCross64;
     if (ring == 4) hipLaunchKernelGGL((k_cross64_mfma<4>), dim3((unsigned)gx, 2), dim3(512), 0, st, T, q, (fq*)partials);
     else hipLaunchKernelGGL((k_cross64_mfma<3>), dim3((unsigned)gx, 2), dim3(512), 0, st, T, q, (fq*)partials);
+    hipLaunchKernelGGL(k_reduce_cross, dim3(160), dim3(kThreads), 0, st, (const fq*)partials, (int)gx, 80, red);
+    hipLaunchKernelGGL(k_cross64_fix, dim3(1), dim3(128), 0, st, (const fq*)red, qn, (fq*)out);
+}
+// launch_fold3_tables followed by launch_cross64 on its result, as one sweep (needs cross64_fits(outlen / 8)); ring = per-wave DMA slots
+void launch_fold3_cross64(const void* const s[4], void* const d[4], size_t outlen, const uint64_t* r3, const uint64_t two24[4], void* wbuf,
+                          int ring, void* partials, void* out, hipStream_t st, const DmaGates& gates) {
+    Tab4 S;
+    Tab4w D;
+    for (int k = 0; k < 4; ++k) { S.t[k] = (const fq*)s[k]; D.t[k] = (fq*)d[k]; }
+    ChalWide ch;
+    for (int l = 0; l < kMaxFoldBatch; ++l) ch.r[l] = l < 3 ? to_fq(r3 + 4 * l) : fq{};
+    ch.two24 = to_fq(two24);
+    hipLaunchKernelGGL(k_eq_weights28, dim3(1), dim3(kThreads), 0, st, ch, 3, (u32*)wbuf);
+    const size_t q = outlen / 8;
+    size_t gx = std::min<size_t>(q / 64, 128);
+    const size_t need = (q + ((size_t)1 << 16) - 1) >> 16;
+    if (gx < need) gx = need;
+    fq* red = (fq*)partials + 2 * gx * 80;
+    fq qn{};
+    qn.v[0] = (u32)q;
+    qn.v[1] = (u32)((u64)q >> 32);
+    const bool stream_stores = gates.wide_stream_from_log < 63 && outlen >= ((size_t)1 << std::max(gates.wide_stream_from_log, 0));
+    g_forms |= kFormFold3Cross64;
+#define ZK_F3X(BV, DV) hipLaunchKernelGGL((k_fold3_cross64<BV, DV>), dim3((unsigned)gx, 2), dim3(512), 0, st, S, D, outlen, (const u32*)wbuf, (fq*)partials)
+    if (stream_stores) { if (ring == 5) ZK_F3X(true, 5); else if (ring == 3) ZK_F3X(true, 3); else ZK_F3X(true, 4); }
+    else { if (ring == 5) ZK_F3X(false, 5); else if (ring == 3) ZK_F3X(false, 3); else ZK_F3X(false, 4); }
+#undef ZK_F3X
     hipLaunchKernelGGL(k_reduce_cross, dim3(160), dim3(kThreads), 0, st, (const fq*)partials, (int)gx, 80, red);
     hipLaunchKernelGGL(k_cross64_fix, dim3(1), dim3(128), 0, st, (const fq*)red, qn, (fq*)out);
 }

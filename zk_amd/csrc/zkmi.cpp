@@ -915,8 +915,14 @@ static int prove_sum2x2_pairs(zk_ctx* c, const void* const tables[4], size_t len
         if ((rc = ensure_work(c, pass & 1, 4 * outlen * kElem))) return rc;
         void* dst[4];
         for (int t = 0; t < 4; ++t) dst[t] = (uint8_t*)c->work[pass & 1] + (size_t)t * outlen * kElem;
-        const int fb = c->gates.deg2_fused_below_log;
-        if (K == 2 && outlen > kHostTail && fb > 0 && outlen < ((size_t)1 << std::min(fb, 62))) {
+        const int fb = c->gates.deg2_fused_below_log, tf = c->gates.deg2_triple_from_log;
+        if (K == 3 && c->gates.deg2_fold3_fused && tf < 63 && outlen >= 512 && outlen >= ((size_t)1 << std::max(tf, 0)) &&
+            zkk::cross64_fits(outlen / 8)) {
+            // the next pass serves three rounds too: its cross sums come out of this fold's sweep
+            ProfScope ps(c, ZK_K_FOLD2X4_SUM9, (uint64_t)curlen * 32 * 4 + (uint64_t)outlen * 32 * 4);
+            zkk::launch_fold3_cross64(cur, dst, outlen, rs, c->two24, c->wide_w, c->gates.deg2_fold3_fused, c->partials, c->sums_host_dev, c->stream,
+                                      c->gates);
+        } else if (K == 2 && outlen > kHostTail && fb > 0 && outlen < ((size_t)1 << std::min(fb, 62))) {
             // small tables: the fold and the nine sums of its result in one launch
             ProfScope ps(c, ZK_K_FOLD2X4_SUM9, (uint64_t)curlen * 32 * 4 + (uint64_t)outlen * 32 * 4);
             uint32_t w28[4 * 10];
@@ -1215,6 +1221,11 @@ int zk_ctx_set_deg2_triple(zk_ctx* c, int from_log, int ring) {
     if (!c || from_log < 0 || from_log > 64 || (ring != 3 && ring != 4)) return ZK_E_ARG;
     c->gates.deg2_triple_from_log = from_log;
     c->gates.deg2_triple_ring = ring;
+    return ZK_OK;
+}
+int zk_ctx_set_deg2_fold3_fused(zk_ctx* c, int dma_slots) {
+    if (!c || (dma_slots != 0 && (dma_slots < 3 || dma_slots > 5))) return ZK_E_ARG;
+    c->gates.deg2_fold3_fused = dma_slots;
     return ZK_OK;
 }
 int zk_ctx_set_deg2_rounds_per_pass(zk_ctx* c, int rounds) {
