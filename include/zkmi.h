@@ -210,6 +210,16 @@ int zk_shard4_fold(zk_shard4 *s, const uint64_t r_mont[4], void *out_dev);
 /* evals: [world][3] elements; coeffs_out: the round polynomial (3 coefficients); host only */
 int zk_sumcheck_round_from_evals(zk_transcript *t, const uint64_t *evals, int world, uint64_t coeffs_out[12],
                                  uint64_t challenge_out[4]);
+/* Three rounds per step (degree-2 branch; see zk_ctx_set_deg2_triple).  zk_shard4_can_triple: 1 if the context's thresholds give the
+ * current tables a three-round pass.  zk_shard4_cross64: cross_dev_out (device, 128 elements) = this shard's share of
+ * P[term][e][e'] = sum_j F_e[j] G_e'[j] (e, e' < 8: the three top variables; tables of >= 512 entries, whole 64-entry eighths).
+ * zk_sumcheck_rounds_from_cross64: sums the ranks' shares ([world][128]) and runs THREE rounds of prover.rs:89-135 on them
+ * (coeffs_out 3 x 3, challenges_out 3 elements).  zk_shard4_fold3: binds the three variables (prover.rs:131-139 three times) and, when
+ * next_dev_out is not NULL, leaves there what the next step needs: *next_rounds_out = 3 (128 cross sums), 2 (nine sums) or 0. */
+int zk_shard4_can_triple(const zk_shard4 *s);
+int zk_shard4_cross64(zk_shard4 *s, void *cross_dev_out);
+int zk_sumcheck_rounds_from_cross64(zk_transcript *t, const uint64_t *cross, int world, uint64_t coeffs_out[36], uint64_t challenges_out[12]);
+int zk_shard4_fold3(zk_shard4 *s, const uint64_t r3[12], void *next_dev_out, int *next_rounds_out);
 /* Two rounds per exchange (the schedule zk_sumcheck_prove_sum2x2 uses on one GPU): each rank's share of the nine
  * sums S[3Y + t] (t: f0*g0, f1*g1, df*dg with the top variable at 0 / 1 / difference; Y in {0,1,2} the value of
  * the second variable; summed over the rest and both product terms -- linear in the entries, so shares add)

@@ -82,6 +82,10 @@ SYMBOLS = [
     ("zk_shard4_sum9", C.c_int, [_VP, _VP]),
     ("zk_sumcheck_round_pair_from_sum9", C.c_int, [_VP, u64p, C.c_int, u64p, u64p]),
     ("zk_shard4_fold2", C.c_int, [_VP, u64p, _VP]),
+    ("zk_shard4_can_triple", C.c_int, [_VP]),
+    ("zk_shard4_cross64", C.c_int, [_VP, _VP]),
+    ("zk_sumcheck_rounds_from_cross64", C.c_int, [_VP, u64p, C.c_int, u64p, u64p]),
+    ("zk_shard4_fold3", C.c_int, [_VP, u64p, _VP, C.POINTER(C.c_int)]),
     ("zk_shard4_copy_tables", C.c_int, [_VP, _VP]),
     ("zk_sumcheck_round_from_evals", C.c_int, [_VP, u64p, C.c_int, u64p, u64p]),
     ("zk_sumcheck_prove_sum2x2_host", C.c_int, [_VP, u64p, C.c_size_t, u64p, u64p]),

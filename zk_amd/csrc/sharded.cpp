@@ -359,15 +359,27 @@ int zki::prove_sum2x2_sharded_dev(zk_ctx* c, const void* const tabs[4], size_t l
     if (gather_log >= 0) { // two rounds per exchange while the local tables are large, then gather the tables
         const unsigned T = std::max(1, gather_log);
         if (ell > T) {
-            if ((rc = zk_shard4_sum9(&s, c->sums_dev))) return rc;
-            while (ell > T) { // ell >= 2
+            // three rounds per exchange (the ranks' shares of the 2 x 64 cross sums: 4 KiB each) while the local tables are large,
+            // two (nine sums) below; the cross sums are sums over the quarter-index, which the low-bit sharding partitions
+            int K = zk_shard4_can_triple(&s) ? 3 : 2;
+            if ((rc = K == 3 ? zk_shard4_cross64(&s, c->sums_dev) : zk_shard4_sum9(&s, c->sums_dev))) return rc;
+            uint64_t r3[12];
+            while (ell > T) { // ell >= 2; a three-round pass only runs on tables of >= 2^9 entries
                 const uint8_t* sums = nullptr;
-                if ((rc = gather_to_host(c, c->sums_dev, 9 * kElem, &sums))) return rc;
-                if ((rc = zk_sumcheck_round_pair_from_sum9(tr, (const uint64_t*)sums, k->world, coeffs_out + 12 * done, rs))) return rc;
-                if (challenges_out) std::memcpy(challenges_out + 4 * done, rs, 2 * kElem);
-                ell -= 2;
-                if ((rc = zk_shard4_fold2(&s, rs, ell > T ? c->sums_dev : nullptr))) return rc;
-                done += 2;
+                if ((rc = gather_to_host(c, c->sums_dev, (K == 3 ? 128 : 9) * kElem, &sums))) return rc;
+                if (K == 3) rc = zk_sumcheck_rounds_from_cross64(tr, (const uint64_t*)sums, k->world, coeffs_out + 12 * done, r3);
+                else rc = zk_sumcheck_round_pair_from_sum9(tr, (const uint64_t*)sums, k->world, coeffs_out + 12 * done, r3);
+                if (rc) return rc;
+                if (challenges_out) std::memcpy(challenges_out + 4 * done, r3, (size_t)K * kElem);
+                ell -= (unsigned)K;
+                done += (unsigned)K;
+                if (K == 3) {
+                    int next = 0;
+                    if ((rc = zk_shard4_fold3(&s, r3, ell > T ? c->sums_dev : nullptr, &next))) return rc;
+                    if (ell > T) K = next; // 3 or 2: the tables keep >= 2^(T+1) >= 4 entries
+                } else if ((rc = zk_shard4_fold2(&s, r3, ell > T ? c->sums_dev : nullptr))) {
+                    return rc;
+                }
             }
         }
         // the four local tables as one contiguous block (they are folded into the context's work buffers next, which the

@@ -872,6 +872,16 @@ static void host_rounds_from_cross(zk_transcript* tr, int K, const Fq* P /* [2][
     }
 }
 
+void zki::host_rounds_from_cross64(zk_transcript* tr, const uint64_t* cross, int world, uint64_t* coeffs_out, uint64_t* rs) {
+    Fq P[128];
+    for (int i = 0; i < 128; ++i) {
+        Fq a = zkh::zero();
+        for (int q = 0; q < world; ++q) a = zkh::add(a, zkh::load(cross + 4 * ((size_t)q * 128 + i)));
+        P[i] = a;
+    }
+    host_rounds_from_cross(tr, 3, P, coeffs_out, rs);
+}
+
 // two (nine sums) or three (8 x 8 cross sums) rounds per device pass
 static int prove_sum2x2_pairs(zk_ctx* c, const void* const tables[4], size_t len, zk_transcript* tr, uint64_t* coeffs_out,
                               uint64_t* challenges_out, uint64_t* final_out) {
@@ -885,8 +895,7 @@ static int prove_sum2x2_pairs(zk_ctx* c, const void* const tables[4], size_t len
     // the sums sweep over four tables of n entries; returns the rounds it serves (3: cross sums, 2: nine sums)
     auto launch_sums = [&](const void* const t[4], size_t n) -> int {
         ProfScope ps(c, ZK_K_SUM9, (uint64_t)n * 32 * 4);
-        const int tf = c->gates.deg2_triple_from_log;
-        if (tf < 63 && n >= 512 && n >= ((size_t)1 << std::max(tf, 0)) && zkk::cross64_fits(n / 8)) {
+        if (deg2_triple_ok(c, n)) {
             zkk::launch_cross64(t, n / 8, c->gates.deg2_triple_ring, c->partials, c->sums_host_dev, c->stream); // 128 cross sums straight into pinned host memory
             return 3;
         }
@@ -915,9 +924,8 @@ static int prove_sum2x2_pairs(zk_ctx* c, const void* const tables[4], size_t len
         if ((rc = ensure_work(c, pass & 1, 4 * outlen * kElem))) return rc;
         void* dst[4];
         for (int t = 0; t < 4; ++t) dst[t] = (uint8_t*)c->work[pass & 1] + (size_t)t * outlen * kElem;
-        const int fb = c->gates.deg2_fused_below_log, tf = c->gates.deg2_triple_from_log;
-        if (K == 3 && c->gates.deg2_fold3_fused && tf < 63 && outlen >= 512 && outlen >= ((size_t)1 << std::max(tf, 0)) &&
-            zkk::cross64_fits(outlen / 8)) {
+        const int fb = c->gates.deg2_fused_below_log;
+        if (K == 3 && c->gates.deg2_fold3_fused && deg2_triple_ok(c, outlen)) {
             // the next pass serves three rounds too: its cross sums come out of this fold's sweep
             ProfScope ps(c, ZK_K_FOLD2X4_SUM9, (uint64_t)curlen * 32 * 4 + (uint64_t)outlen * 32 * 4);
             zkk::launch_fold3_cross64(cur, dst, outlen, rs, c->two24, c->wide_w, c->gates.deg2_fold3_fused, c->partials, c->sums_host_dev, c->stream,
@@ -1113,6 +1121,67 @@ int zk_shard4_fold2(zk_shard4* s, const uint64_t r2[8], void* sums_dev_out) {
     for (int t = 0; t < 4; ++t) s->cur[t] = dst[t];
     s->len = outlen;
     ++s->pass;
+    return ZK_OK;
+}
+
+// ---- three rounds per step (the 8 x 8 cross sums of both terms) -----------------------------------
+int zk_shard4_can_triple(const zk_shard4* s) { return s && deg2_triple_ok(s->ctx, s->len) ? 1 : 0; }
+
+int zk_shard4_cross64(zk_shard4* s, void* cross_dev_out) {
+    if (!s || !cross_dev_out || s->len < 512 || !zkk::cross64_fits(s->len / 8)) return ZK_E_ARG;
+    zk_ctx* c = s->ctx;
+    int rc = set_device(c);
+    if (rc) return rc;
+    {
+        ProfScope ps(c, ZK_K_SUM9, (uint64_t)s->len * 32 * 4);
+        zkk::launch_cross64(s->cur, s->len / 8, c->gates.deg2_triple_ring, c->partials, cross_dev_out, c->stream);
+    }
+    HIPCHK(c, hipGetLastError());
+    return ZK_OK;
+}
+
+int zk_sumcheck_rounds_from_cross64(zk_transcript* t, const uint64_t* cross, int world, uint64_t coeffs_out[36], uint64_t challenges_out[12]) {
+    if (!t || !cross || !coeffs_out || !challenges_out || world < 1) return ZK_E_ARG;
+    host_rounds_from_cross64(t, cross, world, coeffs_out, challenges_out);
+    return ZK_OK;
+}
+
+// bind the three top variables of the four tables at r3[0..3); next_dev_out (may be NULL) receives the sums the next step needs
+// and *next_rounds_out says which: 3 = the 2 x 64 cross sums (128 elements), 2 = the nine sums, 0 = none (tables too short / NULL)
+int zk_shard4_fold3(zk_shard4* s, const uint64_t r3[12], void* next_dev_out, int* next_rounds_out) {
+    if (!s || !r3 || s->len < 512 || (s->len / 8) % 64 != 0) return ZK_E_ARG;
+    zk_ctx* c = s->ctx;
+    int rc = set_device(c);
+    if (rc) return rc;
+    const size_t outlen = s->len / 8;
+    if ((rc = ensure_work(c, s->pass & 1, 4 * outlen * kElem))) return rc;
+    void* dst[4];
+    for (int t = 0; t < 4; ++t) dst[t] = (uint8_t*)c->work[s->pass & 1] + (size_t)t * outlen * kElem;
+    int next = 0;
+    if (next_dev_out && c->gates.deg2_fold3_fused && deg2_triple_ok(c, outlen)) {
+        ProfScope ps(c, ZK_K_FOLD2X4_SUM9, (uint64_t)s->len * 32 * 4 + (uint64_t)outlen * 32 * 4);
+        zkk::launch_fold3_cross64(s->cur, dst, outlen, r3, c->two24, c->wide_w, c->gates.deg2_fold3_fused, c->partials, next_dev_out, c->stream, c->gates);
+        next = 3;
+    } else {
+        {
+            ProfScope ps(c, ZK_K_FOLD2X4_SUM9, (uint64_t)s->len * 32 * 4 + (uint64_t)outlen * 32 * 4);
+            zkk::launch_fold3_tables(s->cur, dst, outlen, r3, c->two24, c->wide_w, c->partials, c->stream, c->gates);
+        }
+        if (next_dev_out && deg2_triple_ok(c, outlen)) {
+            ProfScope ps(c, ZK_K_SUM9, (uint64_t)outlen * 32 * 4);
+            zkk::launch_cross64(dst, outlen / 8, c->gates.deg2_triple_ring, c->partials, next_dev_out, c->stream);
+            next = 3;
+        } else if (next_dev_out && outlen >= 4) {
+            ProfScope ps(c, ZK_K_SUM9, (uint64_t)outlen * 32 * 4);
+            zkk::launch_sum9(dst, outlen / 4, c->two24, c->deg2_lazy_from_log, c->partials, next_dev_out, c->stream, c->gates);
+            next = 2;
+        }
+    }
+    HIPCHK(c, hipGetLastError());
+    for (int t = 0; t < 4; ++t) s->cur[t] = dst[t];
+    s->len = outlen;
+    ++s->pass;
+    if (next_rounds_out) *next_rounds_out = next;
     return ZK_OK;
 }
 

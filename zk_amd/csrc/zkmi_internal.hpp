@@ -146,6 +146,12 @@ inline unsigned next_batch(const zk_ctx* c, unsigned ell) {
     return std::min((unsigned)c->fold_batch, ell);
 }
 
+// degree-2 prover: does a pass over four tables of n entries serve three rounds (8 x 8 cross sums per term) rather than two?
+inline bool deg2_triple_ok(const zk_ctx* c, size_t n) {
+    const int tf = c->gates.deg2_triple_from_log;
+    return tf < 63 && n >= 512 && n >= ((size_t)1 << std::max(tf, 0)) && zkk::cross64_fits(n / 8);
+}
+
 inline int ensure_work(zk_ctx* c, int which, size_t bytes) {
     if (c->work_cap[which] >= bytes) return ZK_OK;
     if (c->work[which]) { HIPCHK(c, hipFree(c->work[which])); c->work[which] = nullptr; c->work_cap[which] = 0; }
@@ -285,6 +291,8 @@ int prove_mle_dev(zk_ctx* c, const void* table, unsigned n, zk_transcript* tr, u
                   uint64_t* challenges_out);
 int prove_sum2x2_dev(zk_ctx* c, const void* const tables[4], size_t len, zk_transcript* tr, uint64_t* coeffs_out,
                      uint64_t* challenges_out, uint64_t* final_out);
+// the host part of three rounds from the ranks' shares of the 2 x 64 cross sums (zkmi.cpp)
+void host_rounds_from_cross64(zk_transcript* tr, const uint64_t* cross, int world, uint64_t* coeffs_out, uint64_t* rs);
 // defined in sharded.cpp: the same for tables sharded over the ranks of the context's communicator (len_local entries per rank)
 int prove_sum2x2_sharded_dev(zk_ctx* c, const void* const tabs[4], size_t len_local, zk_transcript* tr, int gather_log, uint64_t* coeffs_out,
                              uint64_t* challenges_out, uint64_t* final_out);
