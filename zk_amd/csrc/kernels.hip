@@ -1400,6 +1400,7 @@ __global__ void __launch_bounds__(512) k_fold3_cross64(Tab4 S, Tab4w Dst, size_t
     const size_t stride = (size_t)gridDim.x * 64, base0 = (size_t)blockIdx.x * 64;
     const int nt = base0 < qn ? (int)((qn - base0 + stride - 1) / stride) : 0;
     const int nsteps = nt * 16; // source rows of this wave: step s = 16 t + 8 rr + b
+    const bool late = w >= 4;   // wave-uniform
     // rows 2w, 2w + 1 belong to the same factor table (w < 4: F, else G)
     const fq* __restrict__ src = S.t[2 * term + (w >> 2)];
     fq* __restrict__ dst = Dst.t[2 * term + (w >> 2)];
@@ -1423,57 +1424,7 @@ __global__ void __launch_bounds__(512) k_fold3_cross64(Tab4 S, Tab4w Dst, size_t
     for (int k = 0; k < 9; ++k) pl[w][0][k][lane] = pl[w][1][k][lane] = 0;
     const int gg = lane >> 4, qq = (lane >> 1) & 7, pp = lane & 1; // transposed-read address inside a row: see k_sum16_mfma
     const u32 tr_off = (u32)((16 * (gg >> 1) + qq) * 32 + 16 * (gg & 1) + 8 * pp);
-#pragma unroll
-    for (int s = 0; s < D; ++s)
-        if (s < nsteps) issue(s);
-    for (int t = 0; t < nt; ++t) {
-#pragma nounroll
-        for (int rr = 0; rr < 2; ++rr) {
-            u64 a28[20];
-#pragma unroll
-            for (int k = 0; k < 20; ++k) a28[k] = 0;
-            // rolled: one source row at a time (an unrolled loop keeps sixteen row addresses and interleaved rows alive in registers
-            // this kernel does not have)
-#pragma nounroll
-            for (int b = 0; b < 8; ++b) {
-                const int s = 16 * t + 8 * rr + b;
-                // younger than row s when it is waited for: rows s+1 .. s+D-1 (two instructions each) and, for b < D, the two store
-                // instructions of the previous output row (none before the first); the last D rows of a wave drain
-                if (s + D <= nsteps) {
-                    if (b < D && s >= 8) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (D - 1) + 2) : "memory");
-                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (D - 1)) : "memory");
-                } else {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                }
-                const int slot = s % D;
-                const u32x4 lo = ring[w][slot][2 * lane], hi = ring[w][slot][2 * lane + 1];
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // in registers before the slot is refilled
-                if (s + D < nsteps) issue(s + D);
-                fq x;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) { x.v[k] = lo[k]; x.v[4 + k] = hi[k]; }
-                fq28_mac(a28, x, wts + 10 * b);
-            }
-            const fq o = fq28_redc(a28);
-            fq* out = dst + (e0 + (size_t)rr) * qn + base0 + (size_t)t * stride + lane;
-            if (BIG) fq_store_stream(out, o); else fq_store(out, o);
-            if (rr == 0 && t > 0) { // every wave has finished the matrix stage of tile t - 1: the tile buffer is free
-                __builtin_amdgcn_s_barrier();
-                asm volatile("" ::: "memory");
-            }
-            tile[2 * w + rr][2 * lane] = u32x4{o.v[0], o.v[1], o.v[2], o.v[3]};
-            tile[2 * w + rr][2 * lane + 1] = u32x4{o.v[4], o.v[5], o.v[6], o.v[7]};
-            u32 c = 0;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const u32 v = __builtin_addc(pl[w][rr][k][lane], o.v[k], c, &c);
-                pl[w][rr][k][lane] = v;
-            }
-            pl[w][rr][8][lane] += c;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // this wave's two tile rows are written
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
+    auto matrix_stage = [&]() {
         const u32 tb = (u32)(uintptr_t)&tile[0][0];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) { // 32 eighth-indices per step; the G rows in two halves (the operands of four products at a time)
@@ -1509,7 +1460,62 @@ __global__ void __launch_bounds__(512) k_fold3_cross64(Tab4 S, Tab4w Dst, size_t
                 }
             }
         }
+    };
+#pragma unroll
+    for (int s = 0; s < D; ++s)
+        if (s < nsteps) issue(s);
+    for (int t = 0; t < nt; ++t) {
+#pragma nounroll
+        for (int rr = 0; rr < 2; ++rr) {
+            u64 a28[20];
+#pragma unroll
+            for (int k = 0; k < 20; ++k) a28[k] = 0;
+            // rolled: one source row at a time (an unrolled loop keeps sixteen row addresses and interleaved rows alive in registers
+            // this kernel does not have)
+#pragma nounroll
+            for (int b = 0; b < 8; ++b) {
+                const int s = 16 * t + 8 * rr + b;
+                // younger than row s when it is waited for: rows s+1 .. s+D-1 (two instructions each) and, for b < D, the two store
+                // instructions of the previous output row (none before the first); the last D rows of a wave drain
+                if (s + D <= nsteps) {
+                    if (b < D && s >= 8) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (D - 1) + 2) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (D - 1)) : "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                const int slot = s % D;
+                const u32x4 lo = ring[w][slot][2 * lane], hi = ring[w][slot][2 * lane + 1];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // in registers before the slot is refilled
+                if (s + D < nsteps) issue(s + D);
+                fq x;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { x.v[k] = lo[k]; x.v[4 + k] = hi[k]; }
+                fq28_mac(a28, x, wts + 10 * b);
+            }
+            const fq o = fq28_redc(a28);
+            fq* out = dst + (e0 + (size_t)rr) * qn + base0 + (size_t)t * stride + lane;
+            if (BIG) fq_store_stream(out, o); else fq_store(out, o);
+            if (rr == 0 && t > 0) { // every wave has finished the matrix stage of tile t - 1: the tile buffer is free
+                if (late) matrix_stage();
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+            }
+            tile[2 * w + rr][2 * lane] = u32x4{o.v[0], o.v[1], o.v[2], o.v[3]};
+            tile[2 * w + rr][2 * lane + 1] = u32x4{o.v[4], o.v[5], o.v[6], o.v[7]};
+            u32 c = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const u32 v = __builtin_addc(pl[w][rr][k][lane], o.v[k], c, &c);
+                pl[w][rr][k][lane] = v;
+            }
+            pl[w][rr][8][lane] += c;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // this wave's two tile rows are written
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (!late) matrix_stage(); // waves 4..7 run it after the first row of the next tile: a SIMD's two waves alternate pipes
     }
+    if (late && nt > 0) matrix_stage();
     // ---- epilogue: once per wave (as k_cross64_mfma)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads(); // every wave is done with the tiles: they become scratch (4 KiB per wave)
