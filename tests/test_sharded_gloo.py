@@ -235,3 +235,25 @@ def test_host_degree2_prover_matches_oracle():
         c, ch = sharded.prove_sum2x2_host(tr, np.stack(tabs))
         oc, och = O.sumcheck_prove_sum([[tabs[0], tabs[1]], [tabs[2], tabs[3]]], O.fq1(0), otr)
         assert np.array_equal(c, oc) and np.array_equal(ch, och) and tr.peek_digest() == otr.peek_digest()
+
+
+@pytest.mark.parametrize("world,log_n", [(1, 3), (1, 6), (2, 5), (4, 7)])
+def test_three_rounds_from_cross_sums_match_oracle(world, log_n):
+    """zk_sumcheck_rounds_from_cross64 (host only): from the ranks' shares of the 2 x 64 cross sums of the three top variables
+    the first three rounds' coefficients and challenges equal the oracle's (sumcheck/src/prover.rs:89-135 three times)."""
+    n = 1 << log_n
+    tabs = [O.gen_table(SEED + 30 + k, 0, n) for k in range(4)]
+    ints = [O.mont_to_ints(t) for t in tabs]
+    q = n // 8
+    cross = np.empty((world, 2, 8, 8, 4), dtype=np.uint64)
+    for rank in range(world):           # rank r holds the entries whose index is r mod world
+        for term in range(2):
+            F, G = ints[2 * term], ints[2 * term + 1]
+            vals = [sum(F[e * q + j] * G[e2 * q + j] for j in range(rank, q, world)) % P for e in range(8) for e2 in range(8)]
+            cross[rank, term] = O.ints_to_mont(vals).reshape(8, 8, 4)
+    tr, otr = zk_amd.Transcript(), O.OTranscript()
+    tr.append(b"cross")
+    otr.append(b"cross")
+    coeffs, ch = sharded.rounds_from_cross64(tr, cross)
+    oc, och = O.sumcheck_prove_sum([[tabs[0], tabs[1]], [tabs[2], tabs[3]]], O.fq1(0), otr)
+    assert np.array_equal(coeffs, oc[:3]) and np.array_equal(ch, och[:3])

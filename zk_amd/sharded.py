@@ -411,6 +411,16 @@ def round_pair_from_sum9(transcript: Transcript, sums: np.ndarray):
     return coeffs, r
 
 
+def rounds_from_cross64(transcript: Transcript, cross: np.ndarray):
+    """cross (world, 2, 8, 8, 4): the ranks' shares of P[term][e][e'] = sum_j F_e[j] G_e'[j] over the three top variables ->
+    (coefficients (3,3,4), challenges (3,4)); zk_sumcheck_rounds_from_cross64, host only."""
+    cross = np.ascontiguousarray(cross, dtype=np.uint64)
+    coeffs = np.empty((3, 3, 4), dtype=np.uint64)
+    r = np.empty((3, 4), dtype=np.uint64)
+    check(lib().zk_sumcheck_rounds_from_cross64(transcript.h, _ptr(cross), cross.shape[0], _ptr(coeffs), _ptr(r)))
+    return coeffs, r
+
+
 def gather_tables4(local, world: int, dist=None, group=None):
     """all-gather of the ranks' four local tables (4, L, 4) -> the remaining tables (4, world * L, 4), entry
     j*world + q = rank q's entry j."""
