@@ -125,6 +125,16 @@ def test_sum2x2_2pow26_config4_size():
     assert ok and np.array_equal(ch, pts)
     vals = [O.mont_to_ints(t.evaluate([c for c in pts]).get_evaluation_points())[0] for t in tabs]
     assert O.mont_to_ints(final)[0] == (vals[0] * vals[1] + vals[2] * vals[3]) % P
+    # the proof does not depend on the schedule: two rounds per pass throughout, separate fold and sums sweeps
+    ctx = tabs[0].ctx
+    ctx.set_deg2_triple(64, 4)
+    ctx.set_deg2_fused(0)
+    ctx.forms_used()
+    proof1, pts1 = zk_amd.SumcheckProver.generate_proof_for_partial_verify(O.fq1(0), f, zk_amd.Transcript())
+    assert "cross64" not in ctx.forms_used()
+    ctx.set_deg2_triple(21, 4)
+    ctx.set_deg2_fused(20)
+    assert np.array_equal(proof1.round_polys, proof0.round_polys) and np.array_equal(pts1, pts)
 
 
 def test_sumcheck_2pow30_largest_benchmark_size():
