@@ -1227,7 +1227,8 @@ __global__ void __launch_bounds__(64) k_sum9_from_p16(const fq* __restrict__ in4
 // as the reference's per-round sums), and one fold with the eight weights eq((r0,r1,r2), .) binds all three variables: per prove
 // the tables are read 8/7 + (9/8)(8/7) = 2.43 times instead of 3.0 (two rounds per pass).  Same scheme as k_sum16_mfma -- bytes
 // as signed i8, v_mfma_i32_32x32x32_i8 with the contraction over j, operands by ds_read_b64_tr_b8 -- with eight waves per workgroup:
-// wave w keeps C[e = w][e' = 0..7] (128 accumulator registers) and the plain sums of rows F_w and G_w; a tile is 16 rows x 2 KiB,
+// wave w = (wa, wh) keeps the 2 x 4 block C[2 wa + i][4 wh + k] (128 accumulator registers; six operand rows per step instead of the
+// nine of a row-per-wave split: 28 instead of 41 LDS instructions per wave and tile) and the plain sums of rows F_w and G_w; a tile is 16 rows x 2 KiB,
 // staged by LDS-DMA through a ring of R tiles (R - 1 in flight; 32 R KiB of LDS: one workgroup per CU).  Measured at 4 x 2^26: 5.9 TB/s;
 // the same ring with the matrix and LDS work removed 6.2, two 2-tile workgroups per CU 5.3, default instead of nt load policy 5.6.
 // partials: [(term * gridDim.x + bx) * 80 + ...]: 64 values P_signed[e][e'] * 2^-256 (index 8 e + e'), then A_e (8), then B_e' (8).
@@ -1237,6 +1238,7 @@ __global__ void __launch_bounds__(512) k_cross64_mfma(Tab4 T, size_t q, fq* __re
     __shared__ u32x4 sh[R][2 * NE][128];
     const int term = blockIdx.y, lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wa = w & 3, wh = w >> 2; // this wave's products: C[2 wa + i][4 wh + k], i < 2, k < 4 (6 operand rows instead of 9)
     const fq* __restrict__ F = T.t[2 * term];
     const fq* __restrict__ G = T.t[2 * term + 1];
     const size_t stride = (size_t)gridDim.x * 64, base0 = (size_t)blockIdx.x * 64;
@@ -1274,44 +1276,41 @@ __global__ void __launch_bounds__(512) k_cross64_mfma(Tab4 T, size_t q, fq* __re
         if (t + R - 1 < nt) stage(t + R - 1); // into the slot every wave finished reading before this barrier
         const u32 tile = (u32)(uintptr_t)&sh[t % R][0][0];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) { // 32 quarter-indices per step
-            const u32 a0 = tile + (u32)w * 2048u + (u32)ks * 1024u + tr_off;  // row F_w
-            const u32 b0 = tile + (u32)NE * 2048u + (u32)ks * 1024u + tr_off; // rows G_0 .. G_7
-            u64 fa0, fa1, gb[NE][2];
+        for (int ks = 0; ks < 2; ++ks) { // 32 quarter-indices per step; this wave: rows F_2a, F_2a+1 against G_4h .. G_4h+3
+            const u32 a0 = tile + (u32)(2 * wa) * 2048u + (u32)ks * 1024u + tr_off;
+            const u32 b0 = tile + (u32)(NE + 4 * wh) * 2048u + (u32)ks * 1024u + tr_off;
+            u64 fa[2][2], gb[4][2];
             asm volatile(
-                "ds_read_b64_tr_b8 %0, %18\n\t"
-                "ds_read_b64_tr_b8 %1, %18 offset:256\n\t"
-                "ds_read_b64_tr_b8 %2, %19\n\t"
-                "ds_read_b64_tr_b8 %3, %19 offset:256\n\t"
-                "ds_read_b64_tr_b8 %4, %19 offset:2048\n\t"
-                "ds_read_b64_tr_b8 %5, %19 offset:2304\n\t"
-                "ds_read_b64_tr_b8 %6, %19 offset:4096\n\t"
-                "ds_read_b64_tr_b8 %7, %19 offset:4352\n\t"
-                "ds_read_b64_tr_b8 %8, %19 offset:6144\n\t"
-                "ds_read_b64_tr_b8 %9, %19 offset:6400\n\t"
-                "ds_read_b64_tr_b8 %10, %19 offset:8192\n\t"
-                "ds_read_b64_tr_b8 %11, %19 offset:8448\n\t"
-                "ds_read_b64_tr_b8 %12, %19 offset:10240\n\t"
-                "ds_read_b64_tr_b8 %13, %19 offset:10496\n\t"
-                "ds_read_b64_tr_b8 %14, %19 offset:12288\n\t"
-                "ds_read_b64_tr_b8 %15, %19 offset:12544\n\t"
-                "ds_read_b64_tr_b8 %16, %19 offset:14336\n\t"
-                "ds_read_b64_tr_b8 %17, %19 offset:14592\n\t"
+                "ds_read_b64_tr_b8 %0, %12\n\t"
+                "ds_read_b64_tr_b8 %1, %12 offset:256\n\t"
+                "ds_read_b64_tr_b8 %2, %12 offset:2048\n\t"
+                "ds_read_b64_tr_b8 %3, %12 offset:2304\n\t"
+                "ds_read_b64_tr_b8 %4, %13\n\t"
+                "ds_read_b64_tr_b8 %5, %13 offset:256\n\t"
+                "ds_read_b64_tr_b8 %6, %13 offset:2048\n\t"
+                "ds_read_b64_tr_b8 %7, %13 offset:2304\n\t"
+                "ds_read_b64_tr_b8 %8, %13 offset:4096\n\t"
+                "ds_read_b64_tr_b8 %9, %13 offset:4352\n\t"
+                "ds_read_b64_tr_b8 %10, %13 offset:6144\n\t"
+                "ds_read_b64_tr_b8 %11, %13 offset:6400\n\t"
                 "s_waitcnt lgkmcnt(0)"
-                : "=&v"(fa0), "=&v"(fa1), "=&v"(gb[0][0]), "=&v"(gb[0][1]), "=&v"(gb[1][0]), "=&v"(gb[1][1]), "=&v"(gb[2][0]), "=&v"(gb[2][1]),
-                  "=&v"(gb[3][0]), "=&v"(gb[3][1]), "=&v"(gb[4][0]), "=&v"(gb[4][1]), "=&v"(gb[5][0]), "=&v"(gb[5][1]), "=&v"(gb[6][0]),
-                  "=&v"(gb[6][1]), "=&v"(gb[7][0]), "=&v"(gb[7][1])
+                : "=&v"(fa[0][0]), "=&v"(fa[0][1]), "=&v"(fa[1][0]), "=&v"(fa[1][1]), "=&v"(gb[0][0]), "=&v"(gb[0][1]), "=&v"(gb[1][0]),
+                  "=&v"(gb[1][1]), "=&v"(gb[2][0]), "=&v"(gb[2][1]), "=&v"(gb[3][0]), "=&v"(gb[3][1])
                 : "v"(a0), "v"(b0)
                 : "memory");
             const u64 sx = 0x8080808080808080ull;
-            fa0 ^= sx;
-            fa1 ^= sx;
-            const v4i A = v4i{(int)(u32)fa0, (int)(u32)(fa0 >> 32), (int)(u32)fa1, (int)(u32)(fa1 >> 32)};
+            v4i B[4];
 #pragma unroll
-            for (int e = 0; e < NE; ++e) {
-                const u64 x0 = gb[e][0] ^ sx, x1 = gb[e][1] ^ sx;
-                const v4i B = v4i{(int)(u32)x0, (int)(u32)(x0 >> 32), (int)(u32)x1, (int)(u32)(x1 >> 32)};
-                acc[e] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, B, acc[e], 0, 0, 0);
+            for (int k = 0; k < 4; ++k) {
+                const u64 x0 = gb[k][0] ^ sx, x1 = gb[k][1] ^ sx;
+                B[k] = v4i{(int)(u32)x0, (int)(u32)(x0 >> 32), (int)(u32)x1, (int)(u32)(x1 >> 32)};
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const u64 f0 = fa[i][0] ^ sx, f1 = fa[i][1] ^ sx;
+                const v4i A = v4i{(int)(u32)f0, (int)(u32)(f0 >> 32), (int)(u32)f1, (int)(u32)(f1 >> 32)};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc[4 * i + k] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, B[k], acc[4 * i + k], 0, 0, 0);
             }
         }
         { // plain sums: lane l adds entry l of rows F_w and G_w
@@ -1360,7 +1359,7 @@ __global__ void __launch_bounds__(512) k_cross64_mfma(Tab4 T, size_t q, fq* __re
         fq prod = fq_mul(x, wk);
         if (neg) prod = fq_sub(fq_zero(), prod);
         const fq mine = fq_wave_sum(prod);
-        if (lane == 0) fq_store(out + NE * w + e, mine);
+        if (lane == 0) fq_store(out + NE * (2 * wa + (e >> 2)) + 4 * wh + (e & 3), mine);
     }
     fq lo, hi;
 #pragma unroll
