@@ -171,7 +171,7 @@ class OracleShard4:
 
     def sum9(self, out):
         """S[3Y + t]: the table index is (b1, b2, j); F(b1, Y) = F[b1,0] + Y (F[b1,1] - F[b1,0]); f0 = F(0,Y), f1 = F(1,Y),
-        df = f1 - f0; t = 0: f0 g0, 1: f1 g1, 2: df dg; summed over j and both product terms (kernels.hip, k_sum9)"""
+        df = f1 - f0; t = 0: f0 g0, 1: f1 g1, 2: df dg; summed over j and both product terms (deg2_kernels.hip, k_sum9)"""
         q = len(self.t[0]) // 4
         S = [0] * 9
         for j in range(q):

@@ -1,4 +1,4 @@
-// kernels.h -- host-callable launchers of the gfx950 kernels in kernels.hip.
+// kernels.h -- host-callable launchers of the gfx950 kernels in kernels.hip and deg2_kernels.hip.
 // All pointers are device pointers to 32-byte Montgomery elements; `r` is a challenge as
 // 4 x u64 Montgomery limbs (passed to the kernel by value: it lands in SGPRs).
 // Launchers that produce per-block partial sums return the number of blocks launched;
@@ -80,7 +80,7 @@ int launch_sum_all(const void* T, size_t n, void* partials, hipStream_t st);
 int launch_eval3(const void* const t[4], size_t half, void* partials, hipStream_t st);
 int launch_fold4_eval3(const void* const s[4], void* const d[4], size_t q, const uint64_t r[4], void* partials, hipStream_t st);
 void launch_fold4(const void* const s[4], void* const d[4], size_t half, const uint64_t r[4], hipStream_t st);
-// degree-2 branch, two rounds per pass (kernels.hip): out[3Y + t] (9 elements) = the nine sums of four tables of 4q
+// degree-2 branch, two rounds per pass (deg2_kernels.hip): out[3Y + t] (9 elements) = the nine sums of four tables of 4q
 // entries; partials must hold kSum9PartialElems elements
 static constexpr int kMaxBlocks9 = 1024;
 static constexpr size_t kSum9PartialElems = (size_t)160 * kMaxBlocks9 + 256; // elements `partials` must hold for launch_sum9 / launch_cross64

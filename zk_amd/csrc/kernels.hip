@@ -1,4 +1,5 @@
-// kernels.hip -- gfx950 kernels of the multilinear sumcheck prover.
+// kernels.hip -- gfx950 kernels of the multilinear sumcheck prover: the single-MLE path (block sums, multi-variable folds) and the
+// table operations.  The degree-2 (SumPolynomial) branch lives in deg2_kernels.hip; templates both use in kernels_common.hpp.
 //
 // Data layout in HBM: a table is N contiguous 32-byte elements (8 x u32 Montgomery limbs,
 // index order = MultiLinearPolynomial::evaluation_points, variable 0 = most significant index
@@ -8,39 +9,16 @@
 //
 // The big passes are HBM-streaming integer kernels: every byte is read once per pass, so there is nothing to tile for reuse.  LDS
 // is the landing zone of the LDS-DMA streams (per-wave rings) and of the byte-transposed operand reads; the matrix cores are used
-// where a pass is a dense contraction once its operands are cut into bytes (k_multifold_wide_mfma, k_sum16_mfma, k_cross64_mfma).
+// where a pass is a dense contraction once its operands are cut into bytes (k_multifold_wide_mfma here; k_sum16_mfma, k_cross64_mfma
+// and k_fold3_cross64 in deg2_kernels.hip).
 // Grids are capped and grid-stride, block -> per-block partial sums, one small second-stage kernel folds the partials (field
 // addition is exact: results are bit-reproducible whatever the order).
-#include <algorithm>
-#include <cstdlib>
 #include <mutex>
-#include "fq_dev.hpp"
-#include "kernels.h"
+#include "kernels_common.hpp"
 
 namespace zkk {
 
 thread_local unsigned g_forms = 0;
-
-static constexpr int kThreads = 256;
-
-// block-wide sums of NS accumulators; thread 0 of the block writes partials[blockIdx.x*NS + s]
-template <int NS>
-__device__ __forceinline__ void block_sum_store(fq (&acc)[NS], fq* __restrict__ partials) {
-    __shared__ fq lds[NS][kThreads / 64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        fq w = fq_wave_sum(acc[s]);
-        if (lane == 0) lds[s][wave] = w;
-    }
-    __syncthreads();
-    if (threadIdx.x < NS) {
-        fq t = lds[threadIdx.x][0];
-#pragma unroll
-        for (int w = 1; w < kThreads / 64; ++w) t = fq_add(t, lds[threadIdx.x][w]);
-        fq_store(&partials[(size_t)blockIdx.x * NS + threadIdx.x], t);
-    }
-}
 
 // ---- batched rounds: block sums + multi-variable fold -----------------------------------------
 // The MLE-branch round polynomial (sumcheck/src/prover.rs:108-124) only needs the two half sums
@@ -181,7 +159,7 @@ __global__ void __launch_bounds__(kThreads) k_multifold(const fq* __restrict__ s
 // input entry instead of ~119-127 for the tree, which moves this kernel from ALU-bound to HBM-bound.
 // W.w[b] = eq(r,b) * 2^280 mod p as 10 x 28-bit limbs (made on the host).  Same field values as the
 // tree: both are exact.
-template <int M> struct W28 { u32 w[1 << M][10]; };
+// W28<M>: kernels_common.hpp
 
 // Loads are software-pipelined through two register buffers of G elements: while group g is being
 // multiplied into the accumulators, group g+1 (or group 0 of the next grid-stride step) is in flight.
@@ -269,145 +247,10 @@ __global__ void __launch_bounds__(kThreads) k_multifold_lazy(const fq* __restric
 // elements per load buffer keep the kernel at 4 waves per SIMD (the arithmetic, 1.0 ms of a 1.5 ms pass, only
 // hides under the loads with enough waves: 2 waves/SIMD measured 5.2 TB/s, 4 waves 5.6), and the columns are
 // carried once per loop trip so that they stay below 2^64 however many products are summed.
-struct ChalWide {
-    fq r[kMaxFoldBatch];
-    fq two24; // 2^24 in Montgomery form: eq * 2^256 -> eq * 2^280 (fq28_redc divides by 2^280)
-};
-
-// wout[b * 10 + j] = limb j of eq(r, b) * 2^280 mod p, b < 2^m (3 <= m <= 8); challenge l sits on bit m-1-l of b.
-// By one workgroup of kThreads: the trees of the top m/2 and of the remaining variables are built side by side
-// (threads 0-15 and 16-31; level l appends variable l as the new least significant bit; the top tree's root is 2^24,
-// so every weight comes out multiplied by it) and one product per weight joins them: m/2 + 1 dependent products (5 at
-// m = 8) instead of m + 1 -- this chain is on the critical path of every wide and tail pass.
-__device__ __forceinline__ fq chal_pick(const ChalWide& ch, int idx) { // ch.r[idx] without dynamic indexing of kernel arguments
-    fq r = ch.r[0];
-#pragma unroll
-    for (int k = 1; k < kMaxFoldBatch; ++k)
-        if (idx == k) r = ch.r[k];
-    return r;
-}
-// thread b < 2^m of the workgroup gets eq(r, b) * 2^280 mod p as a plain integer (8 words, canonical); every thread of the
-// workgroup must call it (barriers inside)
-__device__ __forceinline__ fq eq_weight_of_thread(const ChalWide& ch, int m) {
-    __shared__ fq half[2][16];
-    const int mh = m >> 1, ml = m - mh; // 1 <= mh <= ml <= 4
-    const int t = threadIdx.x & 15, side = (threadIdx.x >> 4) & 1;
-    const bool builder = threadIdx.x < 32;
-    if (builder && t == 0) {
-        const fq one = {FQ_R_LIMBS};
-        half[side][0] = side ? one : ch.two24;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int l = 0; l < 4; ++l) {
-        const bool act = builder && l < (side ? ml : mh) && t < (1 << l);
-        fq v, hi;
-        if (act) {
-            v = half[side][t];
-            hi = fq_mul(v, chal_pick(ch, side ? mh + l : l));
-        }
-        __syncthreads();
-        if (act) {
-            half[side][2 * t + 1] = hi;
-            half[side][2 * t] = fq_sub(v, hi);
-        }
-        __syncthreads();
-    }
-    if ((int)threadIdx.x < (1 << m)) return fq_mul(half[0][threadIdx.x >> ml], half[1][threadIdx.x & ((1 << ml) - 1)]);
-    return fq_zero();
-}
-__device__ __forceinline__ void eq_weights28_block(const ChalWide& ch, int m, u32* wout) {
-    const fq w = eq_weight_of_thread(ch, m);
-    if ((int)threadIdx.x < (1 << m)) {
-        u32 l28[10];
-        fq28_unpack(w, l28);
-#pragma unroll
-        for (int j2 = 0; j2 < 10; ++j2) wout[threadIdx.x * 10 + j2] = l28[j2];
-    }
-}
+// ChalWide, eq_weight_of_thread, eq_weights28_block: kernels_common.hpp
 __global__ void __launch_bounds__(kThreads) k_eq_weights28(ChalWide ch, int m, u32* __restrict__ wout) { eq_weights28_block(ch, m, wout); }
 
-// The wide pass with its 2^m read streams fed by LDS-DMA (nt policy), as k_block_sums_dma: a wave owns groups of 64
-// consecutive outputs; the 2^m source rows of a group (row b = 64 entries at b * Lout + j, 2 KiB, two DMA instructions)
-// run through the wave's ring of D slots, D - 1 rows in flight behind a counted vmcnt, the stream continuing across
-// the wave's groups.  Lane l reads entry l of the row back from LDS and multiplies it into ITS output's unreduced
-// accumulator with weight b (scalar loads).  No load buffers in registers, no barrier in the loop; the store of a
-// finished group is followed by one vmcnt(0) (stores share the counter) -- once per 2^m rows.  `ring` is the kernel's
-// only __shared__ object.  Lb (outputs per block) must be a multiple of 64.
-template <bool BIG, int D>
-__global__ void __launch_bounds__(kThreads) k_multifold_wide_dma(const fq* __restrict__ src, fq* __restrict__ dst, size_t Lout,
-                                                                  const u32* __restrict__ wts, int m, int log_ob, fq* __restrict__ partials) {
-    __shared__ u32x4 ring[kThreads / 64][D][128];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const unsigned gpb = gridDim.x >> log_ob;
-    const unsigned c = blockIdx.x / gpb, wi = blockIdx.x % gpb;
-    const size_t Lb = Lout >> log_ob, j0 = (size_t)c * Lb;
-    const unsigned ngroups = (unsigned)(Lb >> 6), gstride = gpb * (kThreads / 64);
-    const unsigned nb = 1u << m;
-    auto issue = [&](unsigned group, unsigned b, int slot) {
-        const u32x4* p = reinterpret_cast<const u32x4*>(src + (size_t)b * Lout + j0 + ((size_t)group << 6)) + lane;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
-                                         (__attribute__((address_space(3))) void*)&ring[wave][slot][0], 16, 0, 2);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p + 64),
-                                         (__attribute__((address_space(3))) void*)&ring[wave][slot][64], 16, 0, 2);
-    };
-    const unsigned g0 = wi * (kThreads / 64) + wave;
-    unsigned ig = g0, ib = 0; // next row to issue
-    int inflight = 0;
-#pragma unroll
-    for (int sl = 0; sl < D; ++sl)
-        if (ig < ngroups) {
-            issue(ig, ib, sl);
-            ++inflight;
-            if (++ib == nb) { ib = 0; ig += gstride; }
-        }
-    int slot = 0;
-    fq run = fq_zero();
-    for (unsigned g = g0; g < ngroups; g += gstride) {
-        u64 acc[20];
-#pragma unroll
-        for (int k = 0; k < 20; ++k) acc[k] = 0;
-        const u32* __restrict__ w = wts; // wave-uniform: scalar loads
-        for (unsigned b = 0; b < nb; ++b) {
-            if (inflight == D) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (D - 1)) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const u32x4 lo = ring[wave][slot][2 * lane], hi = ring[wave][slot][2 * lane + 1];
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // in registers before the slot is refilled
-            --inflight;
-            if (ig < ngroups) {
-                issue(ig, ib, slot);
-                ++inflight;
-                if (++ib == nb) { ib = 0; ig += gstride; }
-            }
-            fq x;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { x.v[k] = lo[k]; x.v[4 + k] = hi[k]; }
-            fq28_mac(acc, x, w);
-            if ((b & 15) == 15) fq28_carry(acc); // every 16 products
-            w += 10;
-            slot = slot + 1 == D ? 0 : slot + 1;
-        }
-        const fq o = fq28_redc(acc);
-        fq* out = dst + j0 + ((size_t)g << 6) + lane;
-        if (BIG) fq_store_stream(out, o); else fq_store(out, o);
-        // stores count in vmcnt too.  The counted waits would stay correct without this drain (outstanding loads <= the
-        // counter), but measured without it the m = 2 passes of the degree-2 fold run 5 % slower and m = 8 the same
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        run = fq_add(run, o);
-    }
-    const fq wsum = fq_wave_sum(run);
-    __syncthreads();
-    fq* red = reinterpret_cast<fq*>(&ring[0][0][0]);
-    if (lane == 0) red[wave] = wsum;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        fq t = red[0];
-#pragma unroll
-        for (int k = 1; k < kThreads / 64; ++k) t = fq_add(t, red[k]);
-        fq_store(&partials[blockIdx.x], t);
-    }
-}
+// k_multifold_wide_dma<BIG, D> (the LDS-DMA form of the wide pass; the degree-2 folds use it too): kernels_common.hpp
 
 // The same pass for SMALL outputs (below 2^19 entries: a few waves per CU, time set by each lane's serial chain and by
 // launch latency, tools/wide_g_sweep.sh): every workgroup derives the weights itself into LDS -- no separate
@@ -484,7 +327,6 @@ __global__ void __launch_bounds__(kThreads) k_multifold_wide_lds(const fq* __res
 // which exchange 64-bit partial sums through LDS once per 64 outputs; one radix-2^28 Montgomery reduction per output, as before.
 // K index of lane group g, byte t of its 16-byte fragment: table row b = 2 bp + (g >> 1), byte i = 16 (g & 1) + t -- the 16 bytes
 // the lane reads from the row in LDS; the weight tiles are laid out to match (any K order works if A and B agree).
-typedef int v4i __attribute__((ext_vector_type(4)));
 static constexpr int kMfmaTileWords = 1024; // u32 per b-pair: 4 column tiles x 64 lanes x 4 words
 
 // tiles[((bp * 4 + mt) * 64 + lane) * 4 + u]: word u of lane's fragment of the weight tile (b-pair bp, columns 16 mt .. 16 mt + 15).
@@ -796,933 +638,6 @@ __global__ void __launch_bounds__(kThreads) k_sum_all(const fq* __restrict__ T, 
     block_sum_store<1>(acc, partials);
 }
 
-// ---- degree-2 round reduction for Sum[Prod[A,B], Prod[C,D]] (prover.rs:89-107) -----------
-// For X in {0,1,2}: ev[X] = sum_j  A(X)_j*B(X)_j + C(X)_j*D(X)_j,  T(X)_j = lo_j + X*(hi_j - lo_j),
-// lo = T[j], hi = T[j+half].  X = 2 needs only additions: 2*hi - lo.
-struct Tab4 { const fq* t[4]; };
-struct Tab4w { fq* t[4]; };
-
-__device__ __forceinline__ void eval3_accumulate(fq (&acc)[3], const fq (&lo)[4], const fq (&hi)[4]) {
-    fq x2[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) x2[k] = fq_sub(fq_dbl(hi[k]), lo[k]);
-    acc[0] = fq_add(acc[0], fq_add(fq_mul(lo[0], lo[1]), fq_mul(lo[2], lo[3])));
-    acc[1] = fq_add(acc[1], fq_add(fq_mul(hi[0], hi[1]), fq_mul(hi[2], hi[3])));
-    acc[2] = fq_add(acc[2], fq_add(fq_mul(x2[0], x2[1]), fq_mul(x2[2], x2[3])));
-}
-
-__global__ void __launch_bounds__(kThreads) k_eval3(Tab4 T, size_t half, fq* __restrict__ partials) {
-    fq acc[3] = {fq_zero(), fq_zero(), fq_zero()};
-    const size_t stride = (size_t)gridDim.x * kThreads;
-    for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < half; i += stride) {
-        fq lo[4], hi[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            lo[k] = fq_load_stream(T.t[k] + i);
-            hi[k] = fq_load_stream(T.t[k] + half + i);
-        }
-        eval3_accumulate(acc, lo, hi);
-    }
-    block_sum_store<3>(acc, partials);
-}
-
-// fused: fold all four factor tables at r (prover.rs:131-139) and evaluate the NEXT round's
-// three points from the folded values while they are still in registers.  src tables have 4*q
-// entries, dst tables 2*q.
-__global__ void __launch_bounds__(kThreads) k_fold4_eval3(Tab4 S, Tab4w D, size_t q, fq r, fq* __restrict__ partials) {
-    fq acc[3] = {fq_zero(), fq_zero(), fq_zero()};
-    const size_t stride = (size_t)gridDim.x * kThreads;
-    for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < q; i += stride) {
-        fq lo[4], hi[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            fq a0 = fq_load_stream(S.t[k] + i), a1 = fq_load_stream(S.t[k] + 2 * q + i);
-            lo[k] = fq_fold(a0, a1, r);
-            fq_store(D.t[k] + i, lo[k]);
-            fq b0 = fq_load_stream(S.t[k] + q + i), b1 = fq_load_stream(S.t[k] + 3 * q + i);
-            hi[k] = fq_fold(b0, b1, r);
-            fq_store(D.t[k] + q + i, hi[k]);
-        }
-        eval3_accumulate(acc, lo, hi);
-    }
-    block_sum_store<3>(acc, partials);
-}
-
-// fold of four tables without the evaluation (last round / API use)
-__global__ void __launch_bounds__(kThreads) k_fold4(Tab4 S, Tab4w D, size_t half, fq r) {
-    const size_t stride = (size_t)gridDim.x * kThreads;
-    for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < half; i += stride) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) fq_store(D.t[k] + i, fq_fold(fq_load_stream(S.t[k] + i), fq_load_stream(S.t[k] + half + i), r));
-    }
-}
-
-// ---- degree-2 branch, TWO rounds per pass ---------------------------------------------------------
-// Index = (b1, b2, j): b1, b2 the two top variables, j < q = len/4.  For one product term P = F*G and
-// Y in {0,1,2} let f0 = F(0,Y,j), f1 = F(1,Y,j) (F(b1,Y,j) = F[b1,0,j] + Y (F[b1,1,j] - F[b1,0,j])), df = f1 - f0.
-// After binding b1 := r the term is (f0 + r df)(g0 + r dg) = f0 g0 + r (f1 g1 - f0 g0 - df dg) + r^2 df dg, so
-// the nine sums  S[3Y + 0] = sum f0 g0,  S[3Y + 1] = sum f1 g1,  S[3Y + 2] = sum df dg  (over j and both terms)
-// give BOTH the current round's evaluations (prover.rs:93-100: ev(X) = sum_{Y in {0,1}} [S0 + X (S1-S0-S2) + X^2 S2])
-// and, once r is known, the next round's (ev'(Y) = S0 + r (S1-S0-S2) + r^2 S2): one sweep and one host round
-// trip per TWO rounds, and the fold that follows binds both variables at once.  Same field values as the
-// reference's per-round computation (exact arithmetic).
-// Work split: the fold and the sums are separate sweeps, each spread over as many lanes as the data allows --
-// one lane per (table, output) in the fold, one per (j, term[, Y]) in the sums -- because most calls (GKR layers)
-// run on tables of <= 2^20 entries where the serial chain per lane, not bandwidth, sets the time.
-
-// the three products of one term at one Y from its eight values x[factor][b1][b2]
-template <int Y>
-__device__ __forceinline__ void sum9_products(fq* __restrict__ acc3, const fq (&x)[2][2][2]) {
-    fq v0[2], v1[2], d[2];
-#pragma unroll
-    for (int f = 0; f < 2; ++f) {
-        if (Y == 0) { v0[f] = x[f][0][0]; v1[f] = x[f][1][0]; }
-        else if (Y == 1) { v0[f] = x[f][0][1]; v1[f] = x[f][1][1]; }
-        else { v0[f] = fq_sub(fq_dbl(x[f][0][1]), x[f][0][0]); v1[f] = fq_sub(fq_dbl(x[f][1][1]), x[f][1][0]); }
-        d[f] = fq_sub(v1[f], v0[f]);
-    }
-    acc3[0] = fq_add(acc3[0], fq_mul(v0[0], v0[1]));
-    acc3[1] = fq_add(acc3[1], fq_mul(v1[0], v1[1]));
-    acc3[2] = fq_add(acc3[2], fq_mul(d[0], d[1]));
-}
-
-// YSPLIT = false: gridDim.y = 2 (term); a lane forms all nine products of its term (tables read once): large tables.
-//   partials[(term * gridDim.x + bx) * 9 + 3Y + t]
-// YSPLIT = true:  gridDim.y = 6 (term * 3 + Y); a lane forms the three products of one Y: small tables, 3x the lanes.
-//   partials[((term * 3 + Y) * gridDim.x + bx) * 3 + t]
-template <bool YSPLIT>
-__global__ void __launch_bounds__(kThreads) k_sum9(Tab4 T, size_t q, fq* __restrict__ partials) {
-    constexpr int NS = YSPLIT ? 3 : 9;
-    const int term = YSPLIT ? blockIdx.y / 3 : blockIdx.y;
-    const int Ysel = YSPLIT ? blockIdx.y % 3 : -1;
-    const fq* __restrict__ F = T.t[2 * term];
-    const fq* __restrict__ G = T.t[2 * term + 1];
-    fq acc[NS];
-#pragma unroll
-    for (int s = 0; s < NS; ++s) acc[s] = fq_zero();
-    const size_t stride = (size_t)gridDim.x * kThreads;
-    for (size_t j = (size_t)blockIdx.x * kThreads + threadIdx.x; j < q; j += stride) {
-        fq x[2][2][2];
-        if (!YSPLIT || Ysel != 1) { // b2 = 0 values: needed by Y = 0 and Y = 2
-            x[0][0][0] = fq_load_stream(F + j);
-            x[0][1][0] = fq_load_stream(F + 2 * q + j);
-            x[1][0][0] = fq_load_stream(G + j);
-            x[1][1][0] = fq_load_stream(G + 2 * q + j);
-        }
-        if (!YSPLIT || Ysel != 0) { // b2 = 1 values: needed by Y = 1 and Y = 2
-            x[0][0][1] = fq_load_stream(F + q + j);
-            x[0][1][1] = fq_load_stream(F + 3 * q + j);
-            x[1][0][1] = fq_load_stream(G + q + j);
-            x[1][1][1] = fq_load_stream(G + 3 * q + j);
-        }
-        if (YSPLIT) {
-            if (Ysel == 0) sum9_products<0>(acc, x);
-            else if (Ysel == 1) sum9_products<1>(acc, x);
-            else sum9_products<2>(acc, x);
-        } else {
-            sum9_products<0>(acc + 0, x);
-            sum9_products<1>(acc + (YSPLIT ? 0 : 3), x);
-            sum9_products<2>(acc + (YSPLIT ? 0 : 6), x);
-        }
-    }
-    block_sum_store<NS>(acc, partials + (size_t)blockIdx.y * gridDim.x * NS);
-}
-
-// Large tables: the sums are bound by the 18 field products per quarter-index, not by HBM.  Here the products are
-// accumulated UNREDUCED in radix 2^28 (fq_dev.hpp) -- 82 v_mad_u64_u32 per product and one Montgomery reduction per
-// lane at the very end, instead of a full fq_mul (136 + carries) per product -- and the operands are formed with
-// plain 256-bit additions instead of modular differences: with '+' for "entry at 0 plus entry at 1" (= twice the value
-// at 1/2) the kernel sums  U[a][b] = sum_j F[a][b] G[a][b],  a, b in {0, 1, +}  (a on the top variable, b on the second),
-// nine evaluations of the same biquadratic from which k_sum9_from_u gets the nine S by exact linear maps:
-//   V[a][Y] = U[a][Y] (Y = 0, 1),  V[a][2] = 3 U[a][0] + 6 U[a][1] - 2 U[a][+];   S[3Y + 0] = V[0][Y],  S[3Y + 1] = V[1][Y],
-//   S[3Y + 2] = 2 V[0][Y] + 2 V[1][Y] - V[+][Y]
-// (a quadratic R with R(0), R(1), Q = 4 R(1/2) has leading coefficient 2 R(0) + 2 R(1) - Q and R(2) = 3 R(0) + 6 R(1) - 2 Q).
-// An unreduced accumulator is 20 u64 columns: ONE product per wave.  Block = (64, 9), wave w = 3 b + a forms U[a][b]
-// for the 64 quarter-indices of a tile; 80 VGPRs, two workgroups (18 waves) per CU.  (A form with three accumulators
-// per lane and 3-wave workgroups measured 3.5 % slower: at ~195 VGPRs its six waves per CU sit 2/2/1/1 on the SIMDs
-// and meet at a barrier every step.)  The tiles (64 quarter-indices x 8 entries of the term = 16 KiB) are staged by
-// LDS-DMA (global_load_lds_dwordx4: no VGPR destination) into a ring of three buffers: two tiles are in flight under
-// each tile's arithmetic, every entry is read from HBM exactly once, and all waves take their operands from LDS.
-// Counted vmcnt + raw s_barrier (cdna_hip_programming.md, "Pipelining across barriers"); `sh` is the kernel's only
-// __shared__ object.  The reduction divides by 2^280 instead of 2^256: every lane multiplies its sum by 2^24 (fix24) once.
-//   q must be a multiple of 64.  partials: [((term * 3 + b) * gridDim.x + bx) * 3 + a]
-__device__ __forceinline__ fq lds_elem(const u32x4 (&slot)[2][64], int lane) {
-    const u32x4 lo = slot[0][lane], hi = slot[1][lane];
-    fq x;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) { x.v[w] = lo[w]; x.v[4 + w] = hi[w]; }
-    return x;
-}
-__global__ void __launch_bounds__(576) k_sum9_lazy(Tab4 T, size_t q, fq fix24, fq* __restrict__ partials) {
-    __shared__ u32x4 sh[3][8][2][64];
-    const int term = blockIdx.y, lane = threadIdx.x;
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.y);
-    // which of the nine products this wave forms.  The nine waves of a workgroup sit 3/2/2/2 on the four SIMDs (wave w on
-    // SIMD w % 4) and meet at a barrier every tile, and a product over '+' operands costs 1 or 3 extra 256-bit additions
-    // per factor: the SIMD with three waves (0, 4, 8) gets three of the plain products, the (+,+) product shares a SIMD
-    // with the fourth.  Nibble w of the constant = 3B + A.
-    const int role = (int)((0x375416280ull >> (4 * w)) & 15);
-    const int A = role % 3, B = role / 3; // 0, 1, 2 = '+'
-    const fq* __restrict__ F = T.t[2 * term];
-    const fq* __restrict__ G = T.t[2 * term + 1];
-    u64 acc[20];
-#pragma unroll
-    for (int k = 0; k < 20; ++k) acc[k] = 0;
-    const size_t stride = (size_t)gridDim.x * 64, base0 = (size_t)blockIdx.x * 64;
-    const int nt = base0 < q ? (int)((q - base0 + stride - 1) / stride) : 0;
-    auto stage = [&](int t) { // rows 2w, 2w + 1 (= slot w, both halves) for w < 8
-        if (w < 8) {
-            const size_t j = base0 + (size_t)t * stride + lane;
-            const fq* src = ((w & 4) ? G : F) + (size_t)(w & 3) * q + j;
-            u32x4* buf = &sh[t % 3][w][0][0];
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)reinterpret_cast<const u32x4*>(src),
-                                             (__attribute__((address_space(3))) void*)buf, 16, 0, 2);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(reinterpret_cast<const u32x4*>(src) + 1),
-                                             (__attribute__((address_space(3))) void*)(buf + 64), 16, 0, 2);
-        }
-    };
-    if (nt > 0) stage(0);
-    if (nt > 1) stage(1);
-    int since = 0;
-    for (int t = 0; t < nt; ++t) {
-        if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); // leaves tile t+1's two rows in flight (wave 8 has none)
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (t + 2 < nt) stage(t + 2);
-        const u32x4 (&tile)[8][2][64] = sh[t % 3];
-        // operand of factor f: the sum of its entries over b1 in a's set and b2 in b's set (one, two or four entries)
-        auto opnd = [&](int f) -> fq {
-            const int b1lo = A == 1 ? 1 : 0, b2lo = B == 1 ? 1 : 0;
-            fq x = lds_elem(tile[4 * f + 2 * b1lo + b2lo], lane);
-            if (B == 2) x = fq_add_plain(x, lds_elem(tile[4 * f + 2 * b1lo + 1], lane));
-            if (A == 2) {
-                fq y = lds_elem(tile[4 * f + 2 + b2lo], lane);
-                if (B == 2) y = fq_add_plain(y, lds_elem(tile[4 * f + 3], lane));
-                x = fq_add_plain(x, y);
-            }
-            return x;
-        };
-        u32 lf[10], lg[10];
-        fq28_unpack(opnd(0), lf);
-        fq28_unpack(opnd(1), lg);
-        fq28_mac_vv(acc, lf, lg);
-        if (++since == 8) { // fq28_mac_vv's bound for operands up to 4p
-            since = 0;
-            fq28_carry(acc);
-        }
-    }
-    const fq r = fq_wave_sum(fq_mul(fq28_redc(acc), fix24));
-    if (lane == 0) fq_store(&partials[((size_t)(term * 3 + B) * gridDim.x + blockIdx.x) * 3 + A], r);
-}
-
-// ---- the nine sums on the matrix cores ---------------------------------------------------------------------------------------
-// U[a][b] = sum_j F[a][b] G[a][b] with F[a][b], G[a][b] plain sums of the term's entries e = 2 b1 + b2 at quarter-index j, so every
-// U is a sum of the sixteen cross sums P[e][e'] = sum_j F_e[j] G_e'[j] (as integers of the stored limbs).  Cut into BYTES,
-//   P[e][e'] = sum_{i,i'} 256^(i+i') C[i][i'],   C[i][i'] = sum_j F_e[j].byte[i] * G_e'[j].byte[i'],
-// and C is a 32 x 32 x (number of j) matrix product with the contraction over j: v_mfma_i32_32x32x32_i8 takes 32 quarter-indices
-// per instruction.  Its operands want byte i of 16 consecutive entries per lane -- the transpose of the table's layout -- which
-// ds_read_b64_tr_b8 delivers from the entry-major LDS tile for free (per 16 lanes: 8 rows x 16 byte columns, column-major out;
-// tools/probe_tr8.hip).  Signed bytes: both operands are presented as byte - 128, and
-//   sum_j F G = sum_k 256^k D[k] + 128 c1 (A + B) - 2^14 c1^2 N,   D[k] = sum_{i+i'=k} C_signed[i][i'],  c1 = (2^256 - 1)/255,
-// with A = sum_j F_e[j], B = sum_j G_e'[j] (plain modular sums, one 256-bit add per entry) and N the number of j.  Exact integer
-// arithmetic: the sums are the same field elements as k_sum9 / k_sum9_lazy give.
-// Workgroup = 4 waves on one term; wave w keeps the four accumulators C[e = w][e' = 0..3] (64 registers) and the plain sums of
-// rows F_w and G_w; tiles of 64 quarter-indices (8 rows x 2 KiB) come through a three-tile LDS-DMA ring as in k_sum9_lazy.
-// partials: [(term * gridDim.x + bx) * 24 + ...]: 16 values P_signed[e][e'] * 2^-256 (index 4 e + e'), then A_e (4), then B_e' (4).
-#include "pow256_tab.inc"
-typedef int v16i __attribute__((ext_vector_type(16)));
-
-__global__ void __launch_bounds__(kThreads) k_sum16_mfma(Tab4 T, size_t q, fq* __restrict__ partials) {
-    __shared__ u32x4 sh[3][8][128]; // three tiles x (F_0..F_3, G_0..G_3) x 64 entries x 32 B
-    const int term = blockIdx.y, lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const fq* __restrict__ F = T.t[2 * term];
-    const fq* __restrict__ G = T.t[2 * term + 1];
-    const size_t stride = (size_t)gridDim.x * 64, base0 = (size_t)blockIdx.x * 64;
-    const int nt = base0 < q ? (int)((q - base0 + stride - 1) / stride) : 0;
-    auto stage = [&](int t) { // wave w brings rows 2w, 2w + 1: four DMA instructions
-#pragma unroll
-        for (int r2 = 0; r2 < 2; ++r2) {
-            const int r = 2 * w + r2;
-            const fq* src = ((r & 4) ? G : F) + (size_t)(r & 3) * q + base0 + (size_t)t * stride;
-            const u32x4* p = reinterpret_cast<const u32x4*>(src) + lane;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
-                                             (__attribute__((address_space(3))) void*)&sh[t % 3][r][0], 16, 0, 2);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p + 64),
-                                             (__attribute__((address_space(3))) void*)&sh[t % 3][r][64], 16, 0, 2);
-        }
-    };
-    v16i acc[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e)
-#pragma unroll
-        for (int k = 0; k < 16; ++k) acc[e][k] = 0;
-    u32 sf[9], sg[9]; // plain sums of this lane's entries of rows F_w and G_w (value < 2^256 * tiles)
-#pragma unroll
-    for (int k = 0; k < 9; ++k) sf[k] = sg[k] = 0;
-    // transposed-read address of this lane inside a row: lane 16 gg + 2 qq + pp reads entry 16 (gg >> 1) + qq (+ 8 for the second
-    // read, + 32 for the second K step), bytes 16 (gg & 1) + 8 pp .. + 7
-    const int gg = lane >> 4, qq = (lane >> 1) & 7, pp = lane & 1;
-    const u32 tr_off = (u32)((16 * (gg >> 1) + qq) * 32 + 16 * (gg & 1) + 8 * pp);
-    if (nt > 0) stage(0);
-    if (nt > 1) stage(1);
-    for (int t = 0; t < nt; ++t) {
-        if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); // leaves tile t+1's four instructions in flight
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (t + 2 < nt) stage(t + 2);
-        const u32 tile = (u32)(uintptr_t)&sh[t % 3][0][0];
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) { // 32 quarter-indices per step
-            const u32 a0 = tile + (u32)w * 2048u + (u32)ks * 1024u + tr_off; // row F_w
-            const u32 b0 = tile + 4u * 2048u + (u32)ks * 1024u + tr_off;      // rows G_0 .. G_3
-            u64 fa0, fa1, gb[4][2];
-            asm volatile(
-                "ds_read_b64_tr_b8 %0, %10\n\t"
-                "ds_read_b64_tr_b8 %1, %10 offset:256\n\t"
-                "ds_read_b64_tr_b8 %2, %11\n\t"
-                "ds_read_b64_tr_b8 %3, %11 offset:256\n\t"
-                "ds_read_b64_tr_b8 %4, %11 offset:2048\n\t"
-                "ds_read_b64_tr_b8 %5, %11 offset:2304\n\t"
-                "ds_read_b64_tr_b8 %6, %11 offset:4096\n\t"
-                "ds_read_b64_tr_b8 %7, %11 offset:4352\n\t"
-                "ds_read_b64_tr_b8 %8, %11 offset:6144\n\t"
-                "ds_read_b64_tr_b8 %9, %11 offset:6400\n\t"
-                "s_waitcnt lgkmcnt(0)"
-                : "=&v"(fa0), "=&v"(fa1), "=&v"(gb[0][0]), "=&v"(gb[0][1]), "=&v"(gb[1][0]), "=&v"(gb[1][1]), "=&v"(gb[2][0]), "=&v"(gb[2][1]),
-                  "=&v"(gb[3][0]), "=&v"(gb[3][1])
-                : "v"(a0), "v"(b0)
-                : "memory");
-            const u64 sx = 0x8080808080808080ull;
-            fa0 ^= sx;
-            fa1 ^= sx;
-            const v4i A = v4i{(int)(u32)fa0, (int)(u32)(fa0 >> 32), (int)(u32)fa1, (int)(u32)(fa1 >> 32)};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const u64 x0 = gb[e][0] ^ sx, x1 = gb[e][1] ^ sx;
-                const v4i B = v4i{(int)(u32)x0, (int)(u32)(x0 >> 32), (int)(u32)x1, (int)(u32)(x1 >> 32)};
-                acc[e] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, B, acc[e], 0, 0, 0);
-            }
-        }
-        { // plain sums: lane l adds entry l of rows F_w and G_w
-            const u32x4 flo = sh[t % 3][w][2 * lane], fhi = sh[t % 3][w][2 * lane + 1];
-            const u32x4 glo = sh[t % 3][4 + w][2 * lane], ghi = sh[t % 3][4 + w][2 * lane + 1];
-            u32 c = 0;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) sf[k] = __builtin_addc(sf[k], flo[k], c, &c);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) sf[4 + k] = __builtin_addc(sf[4 + k], fhi[k], c, &c);
-            sf[8] += c;
-            c = 0;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) sg[k] = __builtin_addc(sg[k], glo[k], c, &c);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) sg[4 + k] = __builtin_addc(sg[4 + k], ghi[k], c, &c);
-            sg[8] += c;
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the tile is consumed before its slot is restaged
-        }
-    }
-    // ---- epilogue: once per wave
-    __syncthreads(); // every wave is done with the ring: it becomes scratch (4 KiB per wave)
-    int* mat = reinterpret_cast<int*>(&sh[0][0][0]) + w * 1024;
-    const fq r2 = {FQ_R2_LIMBS};
-    fq mine[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        // C layout of the 32x32 result: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
-#pragma unroll
-        for (int k = 0; k < 16; ++k) mat[((k & 3) + 8 * (k >> 2) + 4 * (lane >> 5)) * 32 + (lane & 31)] = acc[e][k];
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        long long d = 0; // D[k], k = lane: the anti-diagonal i + i' = k (lane 63: empty)
-        const int klo = lane > 31 ? lane - 31 : 0, khi = lane < 31 ? lane : 31;
-        for (int i = klo; i <= khi && lane < 63; ++i) d += mat[i * 32 + (lane - i)];
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        // D[k] * 256^k * 2^-256 mod p: |D| < 2^37 as a field element times the constant, sign restored afterwards
-        const bool neg = d < 0;
-        const unsigned long long ad = (unsigned long long)(neg ? -d : d);
-        fq x = fq_zero();
-        x.v[0] = (u32)ad;
-        x.v[1] = (u32)(ad >> 32);
-        fq wk;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) wk.v[k] = kPow256ModP[lane < 63 ? lane : 0][k];
-        fq prod = fq_mul(x, wk);
-        if (neg) prod = fq_sub(fq_zero(), prod);
-        mine[e] = fq_wave_sum(prod);
-    }
-    // plain sums -> field elements: low 256 bits reduced, the overflow word times 2^256 mod p (fq_mul by R^2 = times R)
-    fq lo, hi;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) lo.v[k] = sf[k];
-    hi = fq_zero();
-    hi.v[0] = sf[8];
-    const fq asum = fq_wave_sum(fq_add(fq_reduce_256(lo), fq_mul(hi, r2)));
-#pragma unroll
-    for (int k = 0; k < 8; ++k) lo.v[k] = sg[k];
-    hi.v[0] = sg[8];
-    const fq bsum = fq_wave_sum(fq_add(fq_reduce_256(lo), fq_mul(hi, r2)));
-    if (lane == 0) {
-        fq* out = partials + ((size_t)term * gridDim.x + blockIdx.x) * 24;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) fq_store(out + 4 * w + e, mine[e]);
-        fq_store(out + 16 + w, asum);
-        fq_store(out + 20 + w, bsum);
-    }
-}
-
-// second stage of k_sum16_mfma: one block per (term, value): out48[term * 24 + v] = sum over the workgroups (fixed order)
-__global__ void __launch_bounds__(kThreads) k_reduce48(const fq* __restrict__ partials, int gx, fq* __restrict__ out48) {
-    const int term = blockIdx.x / 24, v = blockIdx.x % 24;
-    fq acc[1] = {fq_zero()};
-    for (int b = threadIdx.x; b < gx; b += kThreads) acc[0] = fq_add(acc[0], fq_load(partials + ((size_t)term * gx + b) * 24 + v));
-    block_sum_store<1>(acc, out48);
-}
-// 2 x (16 signed cross sums, 4 + 4 plain sums) -> the nine sums S[3Y + t] (through U, as k_sum9_from_u).  One block of 64 threads.
-__global__ void __launch_bounds__(64) k_sum9_from_p16(const fq* __restrict__ in48, fq qn /* the number of quarter-indices, as a plain integer */,
-                                                      fq* __restrict__ out) {
-    __shared__ fq P[2][16];
-    __shared__ fq U[9];
-    const int t = threadIdx.x;
-    if (t < 32) { // P[e][e'] = P_signed + 128 c1 (A_e + B_e') 2^-256 - 2^14 c1^2 N 2^-256
-        const int term = t >> 4, e = (t >> 2) & 3, e2 = t & 3;
-        const fq k1 = {FQ_SUM16_K1}, k2 = {FQ_SUM16_K2};
-        const fq ab = fq_add(fq_load(in48 + term * 24 + 16 + e), fq_load(in48 + term * 24 + 20 + e2));
-        P[term][4 * e + e2] = fq_add(fq_add(fq_load(in48 + term * 24 + 4 * e + e2), fq_mul(k1, ab)), fq_mul(k2, qn));
-    }
-    __syncthreads();
-    if (t < 9) { // U[a][b]: a on the top variable (bit 1 of e), b on the second (bit 0); 0, 1, 2 = '+'
-        const int a = t % 3, b = t / 3;
-        fq u = fq_zero();
-        for (int term = 0; term < 2; ++term)
-            for (int e = 0; e < 4; ++e)
-                for (int e2 = 0; e2 < 4; ++e2) {
-                    const bool in1 = (a == 2 || (e >> 1) == a) && (b == 2 || (e & 1) == b);
-                    const bool in2 = (a == 2 || (e2 >> 1) == a) && (b == 2 || (e2 & 1) == b);
-                    if (in1 && in2) u = fq_add(u, P[term][4 * e + e2]);
-                }
-        U[3 * b + a] = u;
-    }
-    __syncthreads();
-    if (t < 9) {
-        const int Y = t / 3, tt = t % 3;
-        auto V = [&](int a) -> fq { // V[a][Y]
-            if (Y < 2) return U[3 * Y + a];
-            const fq u0 = U[a], u1 = U[3 + a], up = U[6 + a];
-            const fq u1x2 = fq_dbl(u1);
-            return fq_sub(fq_add(fq_add(fq_dbl(u0), u0), fq_add(fq_dbl(u1x2), u1x2)), fq_dbl(up));
-        };
-        fq r;
-        if (tt < 2) r = V(tt);
-        else r = fq_sub(fq_dbl(fq_add(V(0), V(1))), V(2));
-        fq_store(out + t, r);
-    }
-}
-
-// ---- THREE rounds per pass: the 8 x 8 cross sums of a term on the matrix cores -------------------------------------------------
-// With the three top variables as index e = 4 b1 + 2 b2 + b3 (tables of 8 q entries, entry e of quarter-index j at e q + j) the
-// 64 cross sums  P[e][e'] = sum_j F_e[j] G_e'[j]  per term determine THREE rounds on the host (zkmi.cpp, host_rounds_from_cross:
-// round i needs only sum_{e,e'} eq(x,e) eq(x,e') P[e][e'] at x = (r_0..r_{i-1}, X, y) -- exact arithmetic, the same field elements
-// as the reference's per-round sums), and one fold with the eight weights eq((r0,r1,r2), .) binds all three variables: per prove
-// the tables are read 8/7 + (9/8)(8/7) = 2.43 times instead of 3.0 (two rounds per pass).  Same scheme as k_sum16_mfma -- bytes
-// as signed i8, v_mfma_i32_32x32x32_i8 with the contraction over j, operands by ds_read_b64_tr_b8 -- with eight waves per workgroup:
-// wave w = (wa, wh) keeps the 2 x 4 block C[2 wa + i][4 wh + k] (128 accumulator registers; six operand rows per step instead of the
-// nine of a row-per-wave split: 28 instead of 41 LDS instructions per wave and tile) and the plain sums of rows F_w and G_w; a tile is 16 rows x 2 KiB,
-// staged by LDS-DMA through a ring of R tiles (R - 1 in flight; 32 R KiB of LDS: one workgroup per CU).  Measured at 4 x 2^26: 5.9 TB/s;
-// the same ring with the matrix and LDS work removed 6.2, two 2-tile workgroups per CU 5.3, default instead of nt load policy 5.6.
-// partials: [(term * gridDim.x + bx) * 80 + ...]: 64 values P_signed[e][e'] * 2^-256 (index 8 e + e'), then A_e (8), then B_e' (8).
-template <int R>
-__global__ void __launch_bounds__(512) k_cross64_mfma(Tab4 T, size_t q, fq* __restrict__ partials) {
-    constexpr int NE = 8;
-    __shared__ u32x4 sh[R][2 * NE][128];
-    const int term = blockIdx.y, lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wa = w & 3, wh = w >> 2; // this wave's products: C[2 wa + i][4 wh + k], i < 2, k < 4 (6 operand rows instead of 9)
-    const fq* __restrict__ F = T.t[2 * term];
-    const fq* __restrict__ G = T.t[2 * term + 1];
-    const size_t stride = (size_t)gridDim.x * 64, base0 = (size_t)blockIdx.x * 64;
-    const int nt = base0 < q ? (int)((q - base0 + stride - 1) / stride) : 0;
-    auto stage = [&](int t) { // wave w brings rows 2w, 2w + 1: four DMA instructions
-#pragma unroll
-        for (int r2 = 0; r2 < 2; ++r2) {
-            const int r = 2 * w + r2;
-            const fq* src = ((r & NE) ? G : F) + (size_t)(r & (NE - 1)) * q + base0 + (size_t)t * stride;
-            const u32x4* p = reinterpret_cast<const u32x4*>(src) + lane;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
-                                             (__attribute__((address_space(3))) void*)&sh[t % R][r][0], 16, 0, 2);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p + 64),
-                                             (__attribute__((address_space(3))) void*)&sh[t % R][r][64], 16, 0, 2);
-        }
-    };
-    v16i acc[NE];
-#pragma unroll
-    for (int e = 0; e < NE; ++e)
-#pragma unroll
-        for (int k = 0; k < 16; ++k) acc[e][k] = 0;
-    u32 sf[9], sg[9];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) sf[k] = sg[k] = 0;
-    const int gg = lane >> 4, qq = (lane >> 1) & 7, pp = lane & 1; // transposed-read address inside a row: see k_sum16_mfma
-    const u32 tr_off = (u32)((16 * (gg >> 1) + qq) * 32 + 16 * (gg & 1) + 8 * pp);
-#pragma unroll
-    for (int t = 0; t < R - 1; ++t)
-        if (t < nt) stage(t);
-    for (int t = 0; t < nt; ++t) {
-        if (t + R - 2 < nt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (R - 2)) : "memory"); // tiles t+1 .. t+R-2 stay in flight
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (t + R - 1 < nt) stage(t + R - 1); // into the slot every wave finished reading before this barrier
-        const u32 tile = (u32)(uintptr_t)&sh[t % R][0][0];
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) { // 32 quarter-indices per step; this wave: rows F_2a, F_2a+1 against G_4h .. G_4h+3
-            const u32 a0 = tile + (u32)(2 * wa) * 2048u + (u32)ks * 1024u + tr_off;
-            const u32 b0 = tile + (u32)(NE + 4 * wh) * 2048u + (u32)ks * 1024u + tr_off;
-            u64 fa[2][2], gb[4][2];
-            asm volatile(
-                "ds_read_b64_tr_b8 %0, %12\n\t"
-                "ds_read_b64_tr_b8 %1, %12 offset:256\n\t"
-                "ds_read_b64_tr_b8 %2, %12 offset:2048\n\t"
-                "ds_read_b64_tr_b8 %3, %12 offset:2304\n\t"
-                "ds_read_b64_tr_b8 %4, %13\n\t"
-                "ds_read_b64_tr_b8 %5, %13 offset:256\n\t"
-                "ds_read_b64_tr_b8 %6, %13 offset:2048\n\t"
-                "ds_read_b64_tr_b8 %7, %13 offset:2304\n\t"
-                "ds_read_b64_tr_b8 %8, %13 offset:4096\n\t"
-                "ds_read_b64_tr_b8 %9, %13 offset:4352\n\t"
-                "ds_read_b64_tr_b8 %10, %13 offset:6144\n\t"
-                "ds_read_b64_tr_b8 %11, %13 offset:6400\n\t"
-                "s_waitcnt lgkmcnt(0)"
-                : "=&v"(fa[0][0]), "=&v"(fa[0][1]), "=&v"(fa[1][0]), "=&v"(fa[1][1]), "=&v"(gb[0][0]), "=&v"(gb[0][1]), "=&v"(gb[1][0]),
-                  "=&v"(gb[1][1]), "=&v"(gb[2][0]), "=&v"(gb[2][1]), "=&v"(gb[3][0]), "=&v"(gb[3][1])
-                : "v"(a0), "v"(b0)
-                : "memory");
-            const u64 sx = 0x8080808080808080ull;
-            v4i B[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const u64 x0 = gb[k][0] ^ sx, x1 = gb[k][1] ^ sx;
-                B[k] = v4i{(int)(u32)x0, (int)(u32)(x0 >> 32), (int)(u32)x1, (int)(u32)(x1 >> 32)};
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const u64 f0 = fa[i][0] ^ sx, f1 = fa[i][1] ^ sx;
-                const v4i A = v4i{(int)(u32)f0, (int)(u32)(f0 >> 32), (int)(u32)f1, (int)(u32)(f1 >> 32)};
-#pragma unroll
-                for (int k = 0; k < 4; ++k) acc[4 * i + k] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, B[k], acc[4 * i + k], 0, 0, 0);
-            }
-        }
-        { // plain sums: lane l adds entry l of rows F_w and G_w
-            const u32x4 flo = sh[t % R][w][2 * lane], fhi = sh[t % R][w][2 * lane + 1];
-            const u32x4 glo = sh[t % R][NE + w][2 * lane], ghi = sh[t % R][NE + w][2 * lane + 1];
-            u32 c = 0;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) sf[k] = __builtin_addc(sf[k], flo[k], c, &c);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) sf[4 + k] = __builtin_addc(sf[4 + k], fhi[k], c, &c);
-            sf[8] += c;
-            c = 0;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) sg[k] = __builtin_addc(sg[k], glo[k], c, &c);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) sg[4 + k] = __builtin_addc(sg[4 + k], ghi[k], c, &c);
-            sg[8] += c;
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the tile is consumed before its slot is restaged
-        }
-    }
-    // ---- epilogue: once per wave (as k_sum16_mfma)
-    __syncthreads(); // every wave is done with the ring: it becomes scratch (4 KiB per wave)
-    int* mat = reinterpret_cast<int*>(&sh[0][0][0]) + w * 1024;
-    const fq r2 = {FQ_R2_LIMBS};
-    fq* out = partials + ((size_t)term * gridDim.x + blockIdx.x) * (NE * NE + 2 * NE);
-    fq wk;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) wk.v[k] = kPow256ModP[lane < 63 ? lane : 0][k];
-    for (int e = 0; e < NE; ++e) { // rolled: the body is large and runs once
-        v16i a = acc[0];
-#pragma unroll
-        for (int e2 = 1; e2 < NE; ++e2)
-            if (e == e2) a = acc[e2];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) mat[((k & 3) + 8 * (k >> 2) + 4 * (lane >> 5)) * 32 + (lane & 31)] = a[k];
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        long long d = 0; // D[k], k = lane: the anti-diagonal i + i' = k (lane 63: empty)
-        const int klo = lane > 31 ? lane - 31 : 0, khi = lane < 31 ? lane : 31;
-        for (int i = klo; i <= khi && lane < 63; ++i) d += mat[i * 32 + (lane - i)];
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        const bool neg = d < 0;
-        const unsigned long long ad = (unsigned long long)(neg ? -d : d);
-        fq x = fq_zero();
-        x.v[0] = (u32)ad;
-        x.v[1] = (u32)(ad >> 32);
-        fq prod = fq_mul(x, wk);
-        if (neg) prod = fq_sub(fq_zero(), prod);
-        const fq mine = fq_wave_sum(prod);
-        if (lane == 0) fq_store(out + NE * (2 * wa + (e >> 2)) + 4 * wh + (e & 3), mine);
-    }
-    fq lo, hi;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) lo.v[k] = sf[k];
-    hi = fq_zero();
-    hi.v[0] = sf[8];
-    const fq asum = fq_wave_sum(fq_add(fq_reduce_256(lo), fq_mul(hi, r2)));
-#pragma unroll
-    for (int k = 0; k < 8; ++k) lo.v[k] = sg[k];
-    hi.v[0] = sg[8];
-    const fq bsum = fq_wave_sum(fq_add(fq_reduce_256(lo), fq_mul(hi, r2)));
-    if (lane == 0) {
-        fq_store(out + NE * NE + w, asum);
-        fq_store(out + NE * NE + NE + w, bsum);
-    }
-}
-// ---- the three-variable fold FUSED with the next level's cross sums -----------------------------------------------------------------
-// A three-round pass is fold (read 8 entries, write 1) + cross sums of the result (read it again).  Here the fold's outputs go to
-// HBM AND into the LDS tile the matrix stage reads, so the folded tables are not re-read: per prove the tables move 1 + 9/7 = 2.29
-// times instead of 2.43.  A workgroup = 8 waves on one term; per tile of 64 next-level eighth-indices j'' wave w folds the two
-// tile rows r = 2w, 2w + 1 (row r = entry e'' = r & 7 of factor r >> 3: dst[e'' q'' + j''] = sum_b W_b src[b outlen + e'' q'' + j'']),
-// each from eight source rows streamed through the wave's own LDS-DMA ring (D slots of 2 KiB, D - 1 in flight, counted vmcnt: the
-// stream runs on across tiles and under the matrix stage), stores them, writes them into tile buffer t & 1 and adds them to its two
-// plain sums; one s_barrier per tile; then the matrix stage of k_cross64_mfma on the tile (wave w: C[w][0..7]).  Two tile buffers:
-// a wave passes barrier t + 1 only after its matrix stage t, so buffer t & 1 is free when tile t + 2 is written.
-// wts: the eight weights eq((r0,r1,r2), b) * 2^280 as 10 x 28-bit limbs each (k_eq_weights28), scalar loads.
-// partials as k_cross64_mfma: [(term * gridDim.x + bx) * 80 + ...], plain sums at 64 + r.
-template <bool BIG, int D>
-__global__ void __launch_bounds__(512) k_fold3_cross64(Tab4 S, Tab4w Dst, size_t outlen, const u32* __restrict__ wts, fq* __restrict__ partials) {
-    constexpr int NE = 8;
-    __shared__ u32x4 tile[2 * NE][128];  // ONE tile buffer: a second barrier per tile guards its reuse (see below)
-    __shared__ u32x4 ring[8][D][128];
-    __shared__ u32 pl[8][2][9][64];      // per lane: plain sums of the folded rows 2w and 2w + 1 (kept out of the registers)
-    const int term = blockIdx.y, lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const size_t qn = outlen >> 3; // the next level's eighth
-    const size_t stride = (size_t)gridDim.x * 64, base0 = (size_t)blockIdx.x * 64;
-    const int nt = base0 < qn ? (int)((qn - base0 + stride - 1) / stride) : 0;
-    const int nsteps = nt * 16; // source rows of this wave: step s = 16 t + 8 rr + b
-    const bool late = w >= 4;   // wave-uniform
-    // rows 2w, 2w + 1 belong to the same factor table (w < 4: F, else G)
-    const fq* __restrict__ src = S.t[2 * term + (w >> 2)];
-    fq* __restrict__ dst = Dst.t[2 * term + (w >> 2)];
-    const size_t e0 = (size_t)((2 * w) & 7); // entry of row 2w; row 2w + 1: e0 + 1
-    auto issue = [&](int s) {
-        const int t = s >> 4, rr = (s >> 3) & 1, b = s & 7;
-        const fq* p0 = src + (size_t)b * outlen + (e0 + (size_t)rr) * qn + base0 + (size_t)t * stride;
-        const u32x4* p = reinterpret_cast<const u32x4*>(p0) + lane;
-        const int slot = s % D;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
-                                         (__attribute__((address_space(3))) void*)&ring[w][slot][0], 16, 0, 2);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p + 64),
-                                         (__attribute__((address_space(3))) void*)&ring[w][slot][64], 16, 0, 2);
-    };
-    v16i acc[NE];
-#pragma unroll
-    for (int e = 0; e < NE; ++e)
-#pragma unroll
-        for (int k = 0; k < 16; ++k) acc[e][k] = 0;
-#pragma unroll
-    for (int k = 0; k < 9; ++k) pl[w][0][k][lane] = pl[w][1][k][lane] = 0;
-    const int gg = lane >> 4, qq = (lane >> 1) & 7, pp = lane & 1; // transposed-read address inside a row: see k_sum16_mfma
-    const u32 tr_off = (u32)((16 * (gg >> 1) + qq) * 32 + 16 * (gg & 1) + 8 * pp);
-    auto matrix_stage = [&]() {
-        const u32 tb = (u32)(uintptr_t)&tile[0][0];
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) { // 32 eighth-indices per step; the G rows in two halves (the operands of four products at a time)
-            const u32 a0 = tb + (u32)w * 2048u + (u32)ks * 1024u + tr_off;  // row F_w
-            u64 fa0, fa1;
-            asm volatile("ds_read_b64_tr_b8 %0, %2\n\tds_read_b64_tr_b8 %1, %2 offset:256" : "=&v"(fa0), "=&v"(fa1) : "v"(a0) : "memory");
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const u32 b0 = tb + (u32)(NE + 4 * h) * 2048u + (u32)ks * 1024u + tr_off; // rows G_4h .. G_4h+3
-                u64 gb[4][2];
-                asm volatile(
-                    "ds_read_b64_tr_b8 %0, %10\n\t"
-                    "ds_read_b64_tr_b8 %1, %10 offset:256\n\t"
-                    "ds_read_b64_tr_b8 %2, %10 offset:2048\n\t"
-                    "ds_read_b64_tr_b8 %3, %10 offset:2304\n\t"
-                    "ds_read_b64_tr_b8 %4, %10 offset:4096\n\t"
-                    "ds_read_b64_tr_b8 %5, %10 offset:4352\n\t"
-                    "ds_read_b64_tr_b8 %6, %10 offset:6144\n\t"
-                    "ds_read_b64_tr_b8 %7, %10 offset:6400\n\t"
-                    "s_waitcnt lgkmcnt(0)"
-                    : "=&v"(gb[0][0]), "=&v"(gb[0][1]), "=&v"(gb[1][0]), "=&v"(gb[1][1]), "=&v"(gb[2][0]), "=&v"(gb[2][1]), "=&v"(gb[3][0]),
-                      "=&v"(gb[3][1]), "+v"(fa0), "+v"(fa1)
-                    : "v"(b0)
-                    : "memory");
-                const u64 sx = 0x8080808080808080ull;
-                const u64 f0 = fa0 ^ sx, f1 = fa1 ^ sx;
-                const v4i A = v4i{(int)(u32)f0, (int)(u32)(f0 >> 32), (int)(u32)f1, (int)(u32)(f1 >> 32)};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const u64 x0 = gb[e][0] ^ sx, x1 = gb[e][1] ^ sx;
-                    const v4i B = v4i{(int)(u32)x0, (int)(u32)(x0 >> 32), (int)(u32)x1, (int)(u32)(x1 >> 32)};
-                    acc[4 * h + e] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, B, acc[4 * h + e], 0, 0, 0);
-                }
-            }
-        }
-    };
-#pragma unroll
-    for (int s = 0; s < D; ++s)
-        if (s < nsteps) issue(s);
-    for (int t = 0; t < nt; ++t) {
-#pragma nounroll
-        for (int rr = 0; rr < 2; ++rr) {
-            u64 a28[20];
-#pragma unroll
-            for (int k = 0; k < 20; ++k) a28[k] = 0;
-            // rolled: one source row at a time (an unrolled loop keeps sixteen row addresses and interleaved rows alive in registers
-            // this kernel does not have)
-#pragma nounroll
-            for (int b = 0; b < 8; ++b) {
-                const int s = 16 * t + 8 * rr + b;
-                // younger than row s when it is waited for: rows s+1 .. s+D-1 (two instructions each) and, for b < D, the two store
-                // instructions of the previous output row (none before the first); the last D rows of a wave drain
-                if (s + D <= nsteps) {
-                    if (b < D && s >= 8) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (D - 1) + 2) : "memory");
-                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (D - 1)) : "memory");
-                } else {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                }
-                const int slot = s % D;
-                const u32x4 lo = ring[w][slot][2 * lane], hi = ring[w][slot][2 * lane + 1];
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // in registers before the slot is refilled
-                if (s + D < nsteps) issue(s + D);
-                fq x;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) { x.v[k] = lo[k]; x.v[4 + k] = hi[k]; }
-                fq28_mac(a28, x, wts + 10 * b);
-            }
-            const fq o = fq28_redc(a28);
-            fq* out = dst + (e0 + (size_t)rr) * qn + base0 + (size_t)t * stride + lane;
-            if (BIG) fq_store_stream(out, o); else fq_store(out, o);
-            if (rr == 0 && t > 0) { // every wave has finished the matrix stage of tile t - 1: the tile buffer is free
-                if (late) matrix_stage();
-                __builtin_amdgcn_s_barrier();
-                asm volatile("" ::: "memory");
-            }
-            tile[2 * w + rr][2 * lane] = u32x4{o.v[0], o.v[1], o.v[2], o.v[3]};
-            tile[2 * w + rr][2 * lane + 1] = u32x4{o.v[4], o.v[5], o.v[6], o.v[7]};
-            u32 c = 0;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const u32 v = __builtin_addc(pl[w][rr][k][lane], o.v[k], c, &c);
-                pl[w][rr][k][lane] = v;
-            }
-            pl[w][rr][8][lane] += c;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // this wave's two tile rows are written
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (!late) matrix_stage(); // waves 4..7 run it after the first row of the next tile: a SIMD's two waves alternate pipes
-    }
-    if (late && nt > 0) matrix_stage();
-    // ---- epilogue: once per wave (as k_cross64_mfma)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads(); // every wave is done with the tiles: they become scratch (4 KiB per wave)
-    int* mat = reinterpret_cast<int*>(&tile[0][0]) + w * 1024;
-    const fq r2 = {FQ_R2_LIMBS};
-    fq* out = partials + ((size_t)term * gridDim.x + blockIdx.x) * (NE * NE + 2 * NE);
-    fq wk;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) wk.v[k] = kPow256ModP[lane < 63 ? lane : 0][k];
-    for (int e = 0; e < NE; ++e) { // rolled: the body is large and runs once
-        v16i a = acc[0];
-#pragma unroll
-        for (int e2 = 1; e2 < NE; ++e2)
-            if (e == e2) a = acc[e2];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) mat[((k & 3) + 8 * (k >> 2) + 4 * (lane >> 5)) * 32 + (lane & 31)] = a[k];
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        long long d = 0;
-        const int klo = lane > 31 ? lane - 31 : 0, khi = lane < 31 ? lane : 31;
-        for (int i = klo; i <= khi && lane < 63; ++i) d += mat[i * 32 + (lane - i)];
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        const bool neg = d < 0;
-        const unsigned long long ad = (unsigned long long)(neg ? -d : d);
-        fq x = fq_zero();
-        x.v[0] = (u32)ad;
-        x.v[1] = (u32)(ad >> 32);
-        fq prod = fq_mul(x, wk);
-        if (neg) prod = fq_sub(fq_zero(), prod);
-        const fq mine = fq_wave_sum(prod);
-        if (lane == 0) fq_store(out + NE * w + e, mine);
-    }
-#pragma unroll
-    for (int rr = 0; rr < 2; ++rr) {
-        fq lo, hi = fq_zero();
-#pragma unroll
-        for (int k = 0; k < 8; ++k) lo.v[k] = pl[w][rr][k][lane];
-        hi.v[0] = pl[w][rr][8][lane];
-        const fq sum = fq_wave_sum(fq_add(fq_reduce_256(lo), fq_mul(hi, r2)));
-        if (lane == 0) fq_store(out + NE * NE + 2 * w + rr, sum); // rows 0..7 = A_e, rows 8..15 = B_e'
-    }
-}
-
-// second stage: one block per (term, value): red[term * nv + v] = sum over the workgroups (fixed order)
-__global__ void __launch_bounds__(kThreads) k_reduce_cross(const fq* __restrict__ partials, int gx, int nv, fq* __restrict__ red) {
-    const int term = blockIdx.x / nv, v = blockIdx.x % nv;
-    fq acc[1] = {fq_zero()};
-    for (int b = threadIdx.x; b < gx; b += kThreads) acc[0] = fq_add(acc[0], fq_load(partials + ((size_t)term * gx + b) * nv + v));
-    block_sum_store<1>(acc, red);
-}
-// out[term * 64 + 8 e + e'] = P[e][e'] = P_signed + 128 c1 (A_e + B_e') 2^-256 - 2^14 c1^2 N 2^-256 (see k_sum16_mfma); one block of 128
-__global__ void __launch_bounds__(128) k_cross64_fix(const fq* __restrict__ red, fq qn, fq* __restrict__ out) {
-    const int t = threadIdx.x, term = t >> 6, e = (t >> 3) & 7, e2 = t & 7;
-    const fq k1 = {FQ_SUM16_K1}, k2 = {FQ_SUM16_K2};
-    const fq* in = red + term * 80;
-    const fq ab = fq_add(fq_load(in + 64 + e), fq_load(in + 72 + e2));
-    fq_store(out + t, fq_add(fq_add(fq_load(in + 8 * e + e2), fq_mul(k1, ab)), fq_mul(k2, qn)));
-}
-
-// U (in[3 b + a], see k_sum9_lazy) -> the nine sums S[3Y + t].  One block of 64 threads.
-__global__ void __launch_bounds__(64) k_sum9_from_u(const fq* __restrict__ in, fq* __restrict__ out) {
-    const int s = threadIdx.x;
-    if (s >= 9) return;
-    const int Y = s / 3, t = s % 3;
-    auto V = [&](int a) -> fq { // V[a][Y]
-        if (Y < 2) return fq_load(in + 3 * Y + a);
-        const fq u0 = fq_load(in + a), u1 = fq_load(in + 3 + a), up = fq_load(in + 6 + a);
-        const fq u1x2 = fq_dbl(u1);
-        const fq acc = fq_add(fq_add(fq_dbl(u0), u0), fq_add(fq_dbl(u1x2), u1x2)); // 3 u0 + 6 u1
-        return fq_sub(acc, fq_dbl(up));
-    };
-    fq r;
-    if (t < 2) r = V(t);
-    else r = fq_sub(fq_dbl(fq_add(V(0), V(1))), V(2));
-    fq_store(out + s, r);
-}
-
-// second stage: block s = 3Y + t adds its sum's partials over both terms and all bx (fixed order)
-__global__ void __launch_bounds__(kThreads) k_reduce9(const fq* __restrict__ partials, int gx, int ysplit, fq* __restrict__ out) {
-    const int s = blockIdx.x, Y = s / 3, t = s % 3;
-    fq acc[1] = {fq_zero()};
-    for (int i = threadIdx.x; i < 2 * gx; i += kThreads) {
-        const int term = i / gx, bx = i % gx;
-        const size_t at = ysplit ? ((size_t)(term * 3 + Y) * gx + bx) * 3 + t : ((size_t)term * gx + bx) * 9 + s;
-        acc[0] = fq_add(acc[0], fq_load(partials + at));
-    }
-    block_sum_store<1>(acc, out);
-}
-
-// Bind the two top variables of all four tables at once: weights W = eq((r, s), b) * 2^280, b = 2 b1 + b2; one lane per
-// (table = blockIdx.y, output o): dst[o] = sum_b W[b] * src[b * outlen + o], one Montgomery reduction per output.
-__global__ void __launch_bounds__(kThreads) k_fold2_tables(Tab4 S, Tab4w D, size_t outlen, W28<2> W) {
-    const fq* __restrict__ src = S.t[blockIdx.y];
-    fq* __restrict__ dst = D.t[blockIdx.y];
-    const size_t stride = (size_t)gridDim.x * kThreads;
-    for (size_t o = (size_t)blockIdx.x * kThreads + threadIdx.x; o < outlen; o += stride) {
-        const fq in0 = fq_load_stream(src + o), in1 = fq_load_stream(src + outlen + o), in2 = fq_load_stream(src + 2 * outlen + o),
-                 in3 = fq_load_stream(src + 3 * outlen + o);
-        u64 a28[20];
-#pragma unroll
-        for (int k = 0; k < 20; ++k) a28[k] = 0;
-        fq28_mac(a28, in0, W.w[0]);
-        fq28_mac(a28, in1, W.w[1]);
-        fq28_mac(a28, in2, W.w[2]);
-        fq28_mac(a28, in3, W.w[3]);
-        fq_store(dst + o, fq28_redc(a28));
-    }
-}
-
-// Small tables (GKR layers: <= 2^20 entries per table, L2-resident): a pass is bound by launch gaps and by each lane's serial chain,
-// not by bytes, so the two-variable fold and the nine sums of its result are ONE kernel.  A wave serves 16 next-level quarter-indices
-// j' of one term with FOUR lanes each: lane (e, jj) folds entry e q' + j' of both factor tables (8 loads, 8 unreduced products, 2
-// reductions), stores them, and the four lanes of a j' exchange their folded values through LDS (wave-private: program order, no
-// barrier).  Lane e < 3 then forms the three products of Y = e (operands picked by select, not by branch: the wave runs one code
-// path); lane e = 3 contributes zero.  Chain per lane ~1900 vector instructions instead of ~500 + ~1000 in two launches with a
-// second-stage launch between.  partials: [(term * gridDim.x + bx) * 9 + 3Y + t] (k_reduce9, ysplit = 0).
-__global__ void __launch_bounds__(kThreads) k_fold2_sum9(Tab4 S, Tab4w D, size_t outlen, W28<2> W, fq* __restrict__ partials) {
-    __shared__ u32x4 xch[kThreads / 64][2][4][16][2]; // [wave][factor][e][jj][half]: 4 KiB per wave
-    __shared__ fq red[kThreads / 64][9];
-    const int term = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int e = lane >> 4, jj = lane & 15;
-    const fq* __restrict__ F = S.t[2 * term];
-    const fq* __restrict__ G = S.t[2 * term + 1];
-    fq* __restrict__ DF = D.t[2 * term];
-    fq* __restrict__ DG = D.t[2 * term + 1];
-    const size_t qn = outlen >> 2; // next-level quarter length
-    fq acc[3] = {fq_zero(), fq_zero(), fq_zero()};
-    const size_t stride = (size_t)gridDim.x * 64; // j' per grid step
-    for (size_t j0 = (size_t)blockIdx.x * 64 + (size_t)wave * 16; j0 < qn; j0 += stride) { // wave-uniform
-        const size_t j = j0 + jj;
-        const bool live = j < qn;
-        const size_t o = (size_t)e * qn + (live ? j : 0);
-        fq f[4], g[4];
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            f[b] = fq_load(F + (size_t)b * outlen + o);
-            g[b] = fq_load(G + (size_t)b * outlen + o);
-        }
-        u64 a28[20];
-#pragma unroll
-        for (int k = 0; k < 20; ++k) a28[k] = 0;
-#pragma unroll
-        for (int b = 0; b < 4; ++b) fq28_mac(a28, f[b], W.w[b]);
-        const fq fo = fq28_redc(a28);
-#pragma unroll
-        for (int k = 0; k < 20; ++k) a28[k] = 0;
-#pragma unroll
-        for (int b = 0; b < 4; ++b) fq28_mac(a28, g[b], W.w[b]);
-        const fq go = fq28_redc(a28);
-        if (live) {
-            fq_store(DF + o, fo);
-            fq_store(DG + o, go);
-        }
-        xch[wave][0][e][jj][0] = u32x4{fo.v[0], fo.v[1], fo.v[2], fo.v[3]};
-        xch[wave][0][e][jj][1] = u32x4{fo.v[4], fo.v[5], fo.v[6], fo.v[7]};
-        xch[wave][1][e][jj][0] = u32x4{go.v[0], go.v[1], go.v[2], go.v[3]};
-        xch[wave][1][e][jj][1] = u32x4{go.v[4], go.v[5], go.v[6], go.v[7]};
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // wave-private exchange: every lane of the wave has written
-        // operands of Y = e: the b2 = 0 entries (e'' = 0, 2) for Y = 0, the b2 = 1 entries (1, 3) for Y = 1, 2 x[.][1] - x[.][0] for Y = 2
-        fq v0[2], v1[2];
-#pragma unroll
-        for (int fac = 0; fac < 2; ++fac) {
-            fq x[4];
-#pragma unroll
-            for (int ee = 0; ee < 4; ++ee) {
-                const u32x4 lo = xch[wave][fac][ee][jj][0], hi = xch[wave][fac][ee][jj][1];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) { x[ee].v[k] = lo[k]; x[ee].v[4 + k] = hi[k]; }
-            }
-            const fq y20 = fq_sub(fq_dbl(x[1]), x[0]), y21 = fq_sub(fq_dbl(x[3]), x[2]);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                v0[fac].v[k] = e == 0 ? x[0].v[k] : (e == 1 ? x[1].v[k] : y20.v[k]);
-                v1[fac].v[k] = e == 0 ? x[2].v[k] : (e == 1 ? x[3].v[k] : y21.v[k]);
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // values in registers before the next trip overwrites the exchange space
-        const fq d0 = fq_sub(v1[0], v0[0]), d1 = fq_sub(v1[1], v0[1]);
-        const fq p0 = fq_mul(v0[0], v0[1]), p1 = fq_mul(v1[0], v1[1]), p2 = fq_mul(d0, d1);
-        if (live && e < 3) {
-            acc[0] = fq_add(acc[0], p0);
-            acc[1] = fq_add(acc[1], p1);
-            acc[2] = fq_add(acc[2], p2);
-        }
-    }
-    // sums over the 16 lanes of each e, then over the waves
-#pragma unroll
-    for (int t = 0; t < 3; ++t) {
-        fq a = acc[t];
-#pragma unroll
-        for (int off = 8; off > 0; off >>= 1) a = fq_add(a, fq_shfl_down(a, off));
-        if (jj == 0 && e < 3) red[wave][3 * e + t] = a;
-    }
-    __syncthreads();
-    if (threadIdx.x < 9) {
-        fq t = red[0][threadIdx.x];
-#pragma unroll
-        for (int w = 1; w < kThreads / 64; ++w) t = fq_add(t, red[w][threadIdx.x]);
-        fq_store(&partials[((size_t)term * gridDim.x + blockIdx.x) * 9 + threadIdx.x], t);
-    }
-}
-
-// the host tail of the degree-2 prover: four small tables (n entries each) into one contiguous buffer (table-major),
-// normally the device-mapped pinned staging buffer -- one launch instead of four copy commands
-__global__ void __launch_bounds__(kThreads) k_gather4(Tab4 T, size_t n, fq* __restrict__ out) {
-    const size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x;
-    if (i < 4 * n) fq_store(out + i, fq_load(T.t[i / n] + i % n));
-}
-
 // the switch from sharded to replicated passes: gathered local tables (rank-major) -> the remaining tables
 __global__ void __launch_bounds__(kThreads) k_interleave(const fq* __restrict__ in, fq* __restrict__ out, unsigned world, unsigned ntab, size_t L) {
     const size_t total = (size_t)world * ntab * L, stride = (size_t)gridDim.x * kThreads;
@@ -1816,28 +731,11 @@ __global__ void __launch_bounds__(kThreads) k_mad_probe(u32* __restrict__ out, i
 }
 
 // ---- launchers ---------------------------------------------------------------------------
-static inline int grid_for(size_t work) {
-    size_t b = (work + kThreads - 1) / kThreads;
-    if (b < 1) b = 1;
-    if (b > (size_t)kMaxBlocks) b = kMaxBlocks;
-    return (int)b;
-}
-static inline fq to_fq(const uint64_t r[4]) {
-    fq f;
-    for (int i = 0; i < 4; ++i) {
-        f.v[2 * i] = (u32)r[i];
-        f.v[2 * i + 1] = (u32)(r[i] >> 32);
-    }
-    return f;
-}
-
-// grid for a pass whose work is cut into 2^log_ob blocks of Lb entries: a multiple of 2^log_ob
-static inline int grid_blocks(size_t Lb, int log_ob) {
-    size_t per = (Lb + kThreads - 1) / kThreads;
-    size_t cap = (size_t)kMaxBlocks >> log_ob;
-    if (per > cap) per = cap;
-    if (per < 1) per = 1;
-    return (int)(per << log_ob);
+void launch_eq_weights28(const uint64_t* r, int m, const uint64_t two24[4], void* wbuf, hipStream_t st) {
+    ChalWide ch;
+    for (int l = 0; l < kMaxFoldBatch; ++l) ch.r[l] = l < m ? to_fq(r + 4 * l) : fq{};
+    ch.two24 = to_fq(two24);
+    hipLaunchKernelGGL(k_eq_weights28, dim3(1), dim3(kThreads), 0, st, ch, m, (u32*)wbuf);
 }
 int launch_block_sums(const void* T, size_t L, int log_ob, void* partials, void* out, hipStream_t st, const DmaGates& gates) {
     const size_t Lb0 = L >> log_ob;
@@ -1980,194 +878,6 @@ int launch_sum_all(const void* T, size_t n, void* partials, hipStream_t st) {
     int g = grid_for(n);
     hipLaunchKernelGGL(k_sum_all, dim3(g), dim3(kThreads), 0, st, (const fq*)T, n, (fq*)partials);
     return g;
-}
-int launch_eval3(const void* const t[4], size_t half, void* partials, hipStream_t st) {
-    Tab4 T;
-    for (int k = 0; k < 4; ++k) T.t[k] = (const fq*)t[k];
-    int g = grid_for(half);
-    hipLaunchKernelGGL(k_eval3, dim3(g), dim3(kThreads), 0, st, T, half, (fq*)partials);
-    return g;
-}
-int launch_fold4_eval3(const void* const s[4], void* const d[4], size_t q, const uint64_t r[4], void* partials, hipStream_t st) {
-    Tab4 S;
-    Tab4w D;
-    for (int k = 0; k < 4; ++k) { S.t[k] = (const fq*)s[k]; D.t[k] = (fq*)d[k]; }
-    int g = grid_for(q);
-    hipLaunchKernelGGL(k_fold4_eval3, dim3(g), dim3(kThreads), 0, st, S, D, q, to_fq(r), (fq*)partials);
-    return g;
-}
-void launch_fold4(const void* const s[4], void* const d[4], size_t half, const uint64_t r[4], hipStream_t st) {
-    Tab4 S;
-    Tab4w D;
-    for (int k = 0; k < 4; ++k) { S.t[k] = (const fq*)s[k]; D.t[k] = (fq*)d[k]; }
-    hipLaunchKernelGGL(k_fold4, dim3(grid_for(half)), dim3(kThreads), 0, st, S, D, half, to_fq(r));
-}
-void launch_sum9(const void* const t[4], size_t q, const uint64_t fix24[4], int lazy_from_log, void* partials, void* out, hipStream_t st,
-                 const DmaGates& gates) {
-    Tab4 T;
-    for (int k = 0; k < 4; ++k) T.t[k] = (const fq*)t[k];
-    if (gates.sum9_mfma_from_log < 63 && q % 64 == 0 && q >= ((size_t)1 << std::max(gates.sum9_mfma_from_log, 0)) &&
-        q <= ((size_t)kMaxBlocks9 << 16)) { // the matrix cores
-        size_t gx = q / 64;
-        if (gx > (size_t)kMaxBlocks9) gx = kMaxBlocks9;
-        // i32 accumulators hold 2^17 quarter-indices; kMaxBlocks9 workgroups cover q <= 2^26 with 2^16 each (beyond: launch_sum9's caller
-        // would need a larger partials buffer -- the reduced-accumulation kernel takes over)
-        fq* red = (fq*)partials + 2 * gx * 24; // 48 reduced values behind the partials (kSum9PartialElems)
-        fq qn{};
-        qn.v[0] = (u32)q;
-        qn.v[1] = (u32)((u64)q >> 32);
-        g_forms |= kFormSum9Mfma;
-        hipLaunchKernelGGL(k_sum16_mfma, dim3((unsigned)gx, 2), dim3(kThreads), 0, st, T, q, (fq*)partials);
-        hipLaunchKernelGGL(k_reduce48, dim3(48), dim3(kThreads), 0, st, (const fq*)partials, (int)gx, red);
-        hipLaunchKernelGGL(k_sum9_from_p16, dim3(1), dim3(64), 0, st, (const fq*)red, qn, (fq*)out);
-        return;
-    }
-    if (lazy_from_log >= 0 && lazy_from_log < 63 && q >= 64 && q >= ((size_t)1 << lazy_from_log)) { // large: unreduced accumulation, one wave per Y
-        size_t gx = (q + 63) / 64;
-        // 256 workgroups per term (two per CU): this kernel serves the L2-resident sizes (GKR layers: 2^18 quarter-entries), where fewer,
-        // longer-running workgroups beat 1024 short ones (GKR config-5 layers 13.4 -> 12.6 ms, 4 x 2^20 prove 0.389 -> 0.358 ms)
-        if (gx > 256) gx = 256;
-        fq* u = (fq*)partials + (size_t)18 * gx; // nine U sums, behind the partials
-        g_forms |= kFormSum9Lazy;
-        hipLaunchKernelGGL(k_sum9_lazy, dim3((unsigned)gx, 2), dim3(64, 9), 0, st, T, q, to_fq(fix24), (fq*)partials);
-        hipLaunchKernelGGL(k_reduce9, dim3(9), dim3(kThreads), 0, st, (const fq*)partials, (int)gx, 1, u);
-        hipLaunchKernelGGL(k_sum9_from_u, dim3(1), dim3(64), 0, st, (const fq*)u, (fq*)out);
-        return;
-    }
-    size_t gx = (q + kThreads - 1) / kThreads;
-    if (gx < 1) gx = 1;
-    if (gx > (size_t)kMaxBlocks9) gx = kMaxBlocks9;
-    g_forms |= kFormSum9;
-    const bool ysplit = q < ((size_t)1 << 21); // small tables: three times the lanes, tables read twice (mostly cache-resident)
-    if (ysplit) hipLaunchKernelGGL((k_sum9<true>), dim3((unsigned)gx, 6), dim3(kThreads), 0, st, T, q, (fq*)partials);
-    else hipLaunchKernelGGL((k_sum9<false>), dim3((unsigned)gx, 2), dim3(kThreads), 0, st, T, q, (fq*)partials);
-    hipLaunchKernelGGL(k_reduce9, dim3(9), dim3(kThreads), 0, st, (const fq*)partials, (int)gx, ysplit ? 1 : 0, (fq*)out);
-}
-// a workgroup's i32 accumulators take 2^16 quarter-indices: |byte - 128| <= 128, so a product is <= 2^14 and 2^16 of them stay below
-// 2^31 with a factor of two to spare (2^17 all-zero entries would reach exactly 2^31)
-bool cross64_fits(size_t q) { return q >= 64 && q % 64 == 0 && q <= ((size_t)kMaxBlocks9 << 16); }
-void launch_cross64(const void* const t[4], size_t q, int ring, void* partials, void* out, hipStream_t st) {
-    Tab4 T;
-    for (int k = 0; k < 4; ++k) T.t[k] = (const fq*)t[k];
-    // one workgroup per CU and term half: 128 x 2 persistent workgroups; more only to keep a workgroup's share within the i32
-    // accumulators (2^16 quarter-indices)
-    size_t gx = std::min<size_t>(q / 64, 128);
-    const size_t need = (q + ((size_t)1 << 16) - 1) >> 16;
-    if (gx < need) gx = need;
-    fq* red = (fq*)partials + 2 * gx * 80; // 160 reduced values behind the partials (kSum9PartialElems)
-    fq qn{};
-    qn.v[0] = (u32)q;
-    qn.v[1] = (u32)((u64)q >> 32);
-    g_forms |= kFormCross64;
-    if (ring == 4) hipLaunchKernelGGL((k_cross64_mfma<4>), dim3((unsigned)gx, 2), dim3(512), 0, st, T, q, (fq*)partials);
-    else hipLaunchKernelGGL((k_cross64_mfma<3>), dim3((unsigned)gx, 2), dim3(512), 0, st, T, q, (fq*)partials);
-    hipLaunchKernelGGL(k_reduce_cross, dim3(160), dim3(kThreads), 0, st, (const fq*)partials, (int)gx, 80, red);
-    hipLaunchKernelGGL(k_cross64_fix, dim3(1), dim3(128), 0, st, (const fq*)red, qn, (fq*)out);
-}
-// launch_fold3_tables followed by launch_cross64 on its result, as one sweep (needs cross64_fits(outlen / 8)); ring = per-wave DMA slots
-void launch_fold3_cross64(const void* const s[4], void* const d[4], size_t outlen, const uint64_t* r3, const uint64_t two24[4], void* wbuf,
-                          int ring, void* partials, void* out, hipStream_t st, const DmaGates& gates) {
-    Tab4 S;
-    Tab4w D;
-    for (int k = 0; k < 4; ++k) { S.t[k] = (const fq*)s[k]; D.t[k] = (fq*)d[k]; }
-    ChalWide ch;
-    for (int l = 0; l < kMaxFoldBatch; ++l) ch.r[l] = l < 3 ? to_fq(r3 + 4 * l) : fq{};
-    ch.two24 = to_fq(two24);
-    hipLaunchKernelGGL(k_eq_weights28, dim3(1), dim3(kThreads), 0, st, ch, 3, (u32*)wbuf);
-    const size_t q = outlen / 8;
-    size_t gx = std::min<size_t>(q / 64, 128);
-    const size_t need = (q + ((size_t)1 << 16) - 1) >> 16;
-    if (gx < need) gx = need;
-    fq* red = (fq*)partials + 2 * gx * 80;
-    fq qn{};
-    qn.v[0] = (u32)q;
-    qn.v[1] = (u32)((u64)q >> 32);
-    const bool stream_stores = gates.wide_stream_from_log < 63 && outlen >= ((size_t)1 << std::max(gates.wide_stream_from_log, 0));
-    g_forms |= kFormFold3Cross64;
-#define ZK_F3X(BV, DV) hipLaunchKernelGGL((k_fold3_cross64<BV, DV>), dim3((unsigned)gx, 2), dim3(512), 0, st, S, D, outlen, (const u32*)wbuf, (fq*)partials)
-    if (stream_stores) { if (ring == 5) ZK_F3X(true, 5); else if (ring == 3) ZK_F3X(true, 3); else ZK_F3X(true, 4); }
-    else { if (ring == 5) ZK_F3X(false, 5); else if (ring == 3) ZK_F3X(false, 3); else ZK_F3X(false, 4); }
-#undef ZK_F3X
-    hipLaunchKernelGGL(k_reduce_cross, dim3(160), dim3(kThreads), 0, st, (const fq*)partials, (int)gx, 80, red);
-    hipLaunchKernelGGL(k_cross64_fix, dim3(1), dim3(128), 0, st, (const fq*)red, qn, (fq*)out);
-}
-// bind the THREE top variables of four tables of 8 * outlen entries (outlen a multiple of 64): eq weights on the device, then one
-// m = 3 pass of the LDS-DMA fold per table
-void launch_fold3_tables(const void* const s[4], void* const d[4], size_t outlen, const uint64_t* r3, const uint64_t two24[4], void* wbuf,
-                         void* partials, hipStream_t st, const DmaGates& gates) {
-    ChalWide ch;
-    for (int l = 0; l < kMaxFoldBatch; ++l) ch.r[l] = l < 3 ? to_fq(r3 + 4 * l) : fq{};
-    ch.two24 = to_fq(two24);
-    hipLaunchKernelGGL(k_eq_weights28, dim3(1), dim3(kThreads), 0, st, ch, 3, (u32*)wbuf);
-    const bool stream_stores = gates.wide_stream_from_log < 63 && outlen >= ((size_t)1 << std::max(gates.wide_stream_from_log, 0));
-    size_t per = (outlen / 64 + 3) / 4;
-    if (per > 1024) per = 1024;
-    g_forms |= kFormFold3Dma;
-    for (int k = 0; k < 4; ++k) {
-        if (stream_stores)
-            hipLaunchKernelGGL((k_multifold_wide_dma<true, 4>), dim3((unsigned)per), dim3(kThreads), 0, st, (const fq*)s[k], (fq*)d[k], outlen,
-                               (const u32*)wbuf, 3, 0, (fq*)partials);
-        else
-            hipLaunchKernelGGL((k_multifold_wide_dma<false, 4>), dim3((unsigned)per), dim3(kThreads), 0, st, (const fq*)s[k], (fq*)d[k], outlen,
-                               (const u32*)wbuf, 3, 0, (fq*)partials);
-    }
-}
-void launch_gather4(const void* const t[4], size_t n, void* out, hipStream_t st) {
-    Tab4 T;
-    for (int k = 0; k < 4; ++k) T.t[k] = (const fq*)t[k];
-    hipLaunchKernelGGL(k_gather4, dim3((unsigned)((4 * n + kThreads - 1) / kThreads)), dim3(kThreads), 0, st, T, n, (fq*)out);
-}
-// the four weights of a two-variable fold into device memory (for the LDS-DMA fold, which takes them as scalar loads)
-__global__ void __launch_bounds__(64) k_store_w28x4(W28<2> W, u32* __restrict__ out) {
-    if (threadIdx.x < 40) out[threadIdx.x] = W.w[threadIdx.x / 10][threadIdx.x % 10];
-}
-void launch_fold2_tables(const void* const s[4], void* const d[4], size_t outlen, const uint32_t* w28, void* wbuf, void* partials, hipStream_t st,
-                         const DmaGates& gates) {
-    Tab4 S;
-    Tab4w D;
-    for (int k = 0; k < 4; ++k) { S.t[k] = (const fq*)s[k]; D.t[k] = (fq*)d[k]; }
-    W28<2> W;
-    for (int b = 0; b < 4; ++b)
-        for (int j = 0; j < 10; ++j) W.w[b][j] = w28[b * 10 + j];
-    if (wbuf && partials && outlen % 64 == 0 && gates.fold2_from_log < 63 && outlen >= ((size_t)1 << std::max(gates.fold2_from_log, 0))) {
-        g_forms |= kFormFold2Dma;
-        const bool stream_stores = gates.wide_stream_from_log < 63 && outlen >= ((size_t)1 << std::max(gates.wide_stream_from_log, 0));
-        // the largest tables: each table is one m = 2 pass of the LDS-DMA fold (its block sum is not used).  The pass stays
-        // bound by its store stream (1 store per 4 reads): 4.67 -> 4.85 TB/s only, and slower than the lane-per-output
-        // kernel below 2^22 outputs per table
-        hipLaunchKernelGGL(k_store_w28x4, dim3(1), dim3(64), 0, st, W, (u32*)wbuf);
-        size_t per = (outlen / 64 + 3) / 4;
-        if (per > 1024) per = 1024;
-        for (int k = 0; k < 4; ++k) {
-            if (stream_stores)
-                hipLaunchKernelGGL((k_multifold_wide_dma<true, 4>), dim3((unsigned)per), dim3(kThreads), 0, st, S.t[k], D.t[k], outlen, (const u32*)wbuf, 2,
-                                   0, (fq*)partials);
-            else
-                hipLaunchKernelGGL((k_multifold_wide_dma<false, 4>), dim3((unsigned)per), dim3(kThreads), 0, st, S.t[k], D.t[k], outlen,
-                                   (const u32*)wbuf, 2, 0, (fq*)partials);
-        }
-        return;
-    }
-    size_t gx = (outlen + kThreads - 1) / kThreads;
-    if (gx < 1) gx = 1;
-    if (gx > (size_t)kMaxBlocks) gx = kMaxBlocks;
-    g_forms |= kFormFold2Reg;
-    hipLaunchKernelGGL(k_fold2_tables, dim3((unsigned)gx, 4), dim3(kThreads), 0, st, S, D, outlen, W);
-}
-// the fold of launch_fold2_tables and the nine sums of its result (launch_sum9 on d[]) in one launch + the second stage: small tables
-void launch_fold2_sum9(const void* const s[4], void* const d[4], size_t outlen, const uint32_t* w28, void* partials, void* out, hipStream_t st) {
-    Tab4 S;
-    Tab4w D;
-    for (int k = 0; k < 4; ++k) { S.t[k] = (const fq*)s[k]; D.t[k] = (fq*)d[k]; }
-    W28<2> W;
-    for (int b = 0; b < 4; ++b)
-        for (int j = 0; j < 10; ++j) W.w[b][j] = w28[b * 10 + j];
-    size_t gx = (outlen / 4 + 63) / 64;
-    if (gx < 1) gx = 1;
-    if (gx > (size_t)kMaxBlocks9) gx = kMaxBlocks9; // 512 and 256 measure the same on GKR config 5
-    g_forms |= kFormFold2Sum9;
-    hipLaunchKernelGGL(k_fold2_sum9, dim3((unsigned)gx, 2), dim3(kThreads), 0, st, S, D, outlen, W, (fq*)partials);
-    hipLaunchKernelGGL(k_reduce9, dim3(9), dim3(kThreads), 0, st, (const fq*)partials, (int)gx, 0, (fq*)out);
 }
 void launch_interleave(const void* in, void* out, int world, int ntab, size_t L, hipStream_t st) {
     hipLaunchKernelGGL(k_interleave, dim3(grid_for((size_t)world * ntab * L)), dim3(kThreads), 0, st, (const fq*)in, (fq*)out, (unsigned)world,

@@ -807,7 +807,7 @@ static int prove_sum2x2_single(zk_ctx* c, const void* const tables[4], size_t le
     return ZK_OK;
 }
 
-// the host part of two rounds from the nine sums S[3Y + t] (kernels.hip, "degree-2 branch, TWO rounds per pass")
+// the host part of two rounds from the nine sums S[3Y + t] (deg2_kernels.hip, "degree-2 branch, TWO rounds per pass")
 static void host_round_pair_from_sum9(zk_transcript* tr, const Fq S[9], uint64_t* coeffs_out /* 2 x 3 */, uint64_t rs[8]) {
     // round k binds b1: ev(X) = sum_{Y in {0,1}} [S0 + X (S1 - S0 - S2) + X^2 S2](Y)
     Fq mid[3]; // S1 - S0 - S2 per Y
@@ -833,7 +833,7 @@ static void host_round_pair_from_sum9(zk_transcript* tr, const Fq S[9], uint64_t
 }
 
 // the host part of K rounds from the cross sums P[term][e][e'] = sum_j F_e[j] G_e'[j] (e, e' < 2^K index the K top variables, the
-// first to bind on the most significant bit; kernels.hip, k_cross64_mfma).  With x the point of the K variables,
+// first to bind on the most significant bit; deg2_kernels.hip, k_cross64_mfma).  With x the point of the K variables,
 // sum_j F(x, j) G(x, j) = sum_{e,e'} eq(x, e) eq(x, e') P[e][e'], so round i (r_0..r_{i-1} bound, X free, the rest y boolean) reads
 // only the entries whose remaining bits agree:  ev(X) = sum_y sum_{a,a'} L_a(X) L_a'(X) Q[(a,y)][(a',y)],  L_0 = 1 - X, L_1 = X,
 // and binding r contracts Q's top bit on both sides.  Exact arithmetic: the evaluations are the field elements prover.rs:93-100 sums.
