@@ -470,7 +470,26 @@ def bench_sharded(args, zk_amd, np, dist, rank, local_rank, world):
     use_lib = args.sharded_impl == "lib"
     ctx = zk_amd.Context(local_rank) if use_lib else sharded.torch_stream_context(local_rank)
     apply_knobs(args, ctx)
-    transport = sharded.comm_init(ctx, dist) if use_lib else ("rccl" if dist.get_backend() == "nccl" else "host")
+    fallback = None
+    if use_lib:
+        # the library's own communicator; if any rank cannot set it up (ZK_E_COMM: RCCL missing or refusing), every rank falls back to
+        # the torch.distributed loop of zk_amd/sharded.py together, and the line says so
+        try:
+            transport, err = sharded.comm_init(ctx, dist), None
+        except Exception as e:  # noqa: BLE001 -- reported in the JSON line
+            transport, err = None, repr(e)
+        flag = torch.tensor([0 if err else 1], dtype=torch.int32,
+                            device=torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            if err is None:
+                sharded.comm_destroy(ctx)
+            fallback = err or "another rank could not set up the library communicator"
+            use_lib = False
+            ctx = sharded.torch_stream_context(local_rank)
+            apply_knobs(args, ctx)
+    if not use_lib:
+        transport = "rccl" if dist.get_backend() == "nccl" else "host"
     gather_log = args.gather_log if args.gather_log >= 0 else None
     base = zk_amd.Transcript()
     base.append(b"bench: table absorb skipped (sharded run; SURVEY.md H1)")
@@ -557,7 +576,7 @@ def bench_sharded(args, zk_amd, np, dist, rank, local_rank, world):
         sharded.comm_destroy(ctx)
     return {
         "elems_per_s": (1 << log_total) / (ms_per_step * 1e-3), "ms_per_step": ms_per_step, "roofline": roofline,
-        "kernels": kernels, "proof_check": {"all_ranks_identical": same}, "transport": transport,
+        "kernels": kernels, "proof_check": {"all_ranks_identical": same}, "transport": transport, "sharded_impl_fallback": fallback,
         "config": {"workload": f"{what} sharded over {world} GPUs (2^{log_total - g} per GPU, low-bit sharding)",
                    "log_n": log_total, "field": "BN254 Fq", "parallelism": f"table-sharded x{world}",
                    "exchange": exchange,
