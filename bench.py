@@ -47,6 +47,7 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra workloads (size sweep, degree 2, GKR) of the single-GPU line")
     ap.add_argument("--cpu-log-n", type=int, default=24, help="bounded CPU sample size (2^k entries)")
+    ap.add_argument("--cpu-full-log", type=int, default=None, help="one more CPU sample at 2^k entries (SURVEY 8d: 2^28 once; tens of seconds, ~26 GiB)")
     ap.add_argument("--fold-batch", type=int, default=0, help="rounds bound per device pass (0 = library default)")
     ap.add_argument("--wide-batch", type=int, default=-1, help="rounds bound by a pass over a large table (5..8, 0 = off, -1 = library default 8)")
     ap.add_argument("--wide-min-log-out", type=int, default=16, help="wide passes are taken while the folded table keeps >= 2^k entries")
@@ -63,8 +64,8 @@ def parse(argv=None):
     ap.add_argument("--deg2-mfma-from", type=int, default=None, help="degree-2 prover: nine sums on the matrix cores from 2^k quarter-entries (64 = never)")
     ap.add_argument("--deg2-triple-from", type=int, default=None, help="degree-2 prover: three rounds per pass on tables of >= 2^k entries (64 = never)")
     ap.add_argument("--deg2-fused-below", type=int, default=None, help="degree-2 prover: fold + nine sums in one kernel for folded tables below 2^k entries (0 = never)")
-    ap.add_argument("--deg2-fold3-fused", type=int, default=None, help="degree-2 prover: three-variable fold fused with the next cross sums (0 = off, 4..6 = DMA slots per wave)")
-    ap.add_argument("--deg2-triple-ring", type=int, default=3, help="LDS tiles of the three-round sweep (3 or 4)")
+    ap.add_argument("--deg2-fold3-fused", type=int, default=None, help="degree-2 prover: three-variable fold fused with the next cross sums (0 = off, 3..5 = DMA slots per wave)")
+    ap.add_argument("--deg2-triple-ring", type=int, default=None, help="LDS tiles of the three-round sweep (3 or 4; default: the library's, 4)")
     ap.add_argument("--weak", action="store_true", help="multi-GPU: 2^log_n entries PER GPU instead of in total")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend of the ranks' rendezvous (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--shared-device", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
@@ -103,30 +104,53 @@ def launch_ranks(args) -> int:
 
 
 # ------------------------------------------------------------------------------------------------ CPU baseline
-def cpu_baseline(log_n: int):
+def cpu_baseline(log_n: int, extra_logs=(16, 20), full_log=None):
     """The CPU oracle (reference-faithful C restatement, single thread like the reference) timed
     on this host: a reported baseline, never the thing measured above.  A second figure times an honestly
     optimised CPU variant (oracle/fast.c: in-place fused fold, OpenMP) so the ratio is not inflated by the
-    reference's per-round copies."""
+    reference's per-round copies.  SURVEY.md 8(d): samples at 2^16, 2^20, 2^24 always (`samples`); 2^28 once
+    (--cpu-full-log 28: tens of seconds and ~26 GiB, so not in the default run; profiles/ keeps that run's line)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import numpy as np
     import oracle_lib as O
 
-    n = 1 << log_n
-    table = O.gen_table(SEED, 0, n)
     claim = np.empty(4, dtype=np.uint64)
-    out = {}
-    for absorb, key in ((0, "round_loop"), (1, "with_table_absorb")):
-        t0 = time.perf_counter()
-        rc = O.lib().orc_sumcheck_prove_timed(O.ptr(table), C.c_size_t(n), C.c_int(absorb), O.ptr(claim))
-        dt = time.perf_counter() - t0
-        assert rc == 0
-        out[key] = dt
     threads = min(16, os.cpu_count() or 1, O.lib().orc_max_threads())  # the box's CPU share for one GPU
-    O.sumcheck_prove_fast(table[: 1 << 16], absorb=False, threads=threads)  # spin the thread pool up
-    t0 = time.perf_counter()
-    O.sumcheck_prove_fast(table, absorb=False, threads=threads)
-    fast = time.perf_counter() - t0
+
+    def sample(lg, with_absorb=True, with_fast=True):
+        n = 1 << lg
+        table = O.gen_table(SEED, 0, n)
+        reps = max(1, min(32, (1 << 20) >> lg))   # small tables: best of a few runs, they finish in microseconds
+        out = {"log_n": lg}
+        for absorb, key in ((0, "round_loop_ms"), (1, "with_table_absorb_ms")):
+            if absorb and not with_absorb:
+                continue
+            best = None
+            for _ in range(reps):
+                t0 = time.perf_counter()
+                rc = O.lib().orc_sumcheck_prove_timed(O.ptr(table), C.c_size_t(n), C.c_int(absorb), O.ptr(claim))
+                dt = time.perf_counter() - t0
+                assert rc == 0
+                best = dt if best is None else min(best, dt)
+            out[key] = best * 1e3
+        out["elems_per_s"] = n / (out["round_loop_ms"] * 1e-3)
+        if with_fast:
+            O.sumcheck_prove_fast(table[: 1 << min(lg, 16)], absorb=False, threads=threads)  # spin the thread pool up
+            best = None
+            for _ in range(reps):
+                t0 = time.perf_counter()
+                O.sumcheck_prove_fast(table, absorb=False, threads=threads)
+                dt = time.perf_counter() - t0
+                best = dt if best is None else min(best, dt)
+            out["optimised_ms"] = best * 1e3
+            out["optimised_elems_per_s"] = n / best
+        return out
+
+    samples = [sample(lg) for lg in sorted(set(extra_logs) | {log_n})]
+    main = next(x for x in samples if x["log_n"] == log_n)
+    if full_log is not None and full_log > log_n:
+        samples.append(sample(full_log, with_absorb=False))
+    n = 1 << log_n
     cpu_model = ""
     try:
         with open("/proc/cpuinfo") as f:
@@ -137,15 +161,63 @@ def cpu_baseline(log_n: int):
     except OSError:
         pass
     return {
-        "value": n / out["round_loop"], "unit": "field elems/s", "cores": 1, "kind": "port",
+        "value": main["elems_per_s"], "unit": "field elems/s", "cores": 1, "kind": "port",
         "sample": f"2^{log_n}-entry single-MLE sumcheck, round loop only (generate_round_polys): "
-                  f"{out['round_loop'] * 1e3:.0f} ms; reference entry point incl. table absorb "
-                  f"(generate_sumcheck_proof): {out['with_table_absorb'] * 1e3:.0f} ms "
-                  f"= {n / out['with_table_absorb']:.3g} elems/s; C restatement of the Rust prover, 1 thread",
-        "optimised_variant": {"value": n / fast, "unit": "field elems/s", "cores": threads, "kind": "port",
-                              "sample": f"same 2^{log_n} round loop, in-place fused fold + OpenMP ({threads} threads): {fast * 1e3:.0f} ms"},
+                  f"{main['round_loop_ms']:.0f} ms; reference entry point incl. table absorb "
+                  f"(generate_sumcheck_proof): {main['with_table_absorb_ms']:.0f} ms "
+                  f"= {n / (main['with_table_absorb_ms'] * 1e-3):.3g} elems/s; C restatement of the Rust prover, 1 thread",
+        "optimised_variant": {"value": main["optimised_elems_per_s"], "unit": "field elems/s", "cores": threads, "kind": "port",
+                              "sample": f"same 2^{log_n} round loop, in-place fused fold + OpenMP ({threads} threads): {main['optimised_ms']:.0f} ms"},
+        "samples": samples,
+        "samples_note": "per size: faithful restatement on 1 thread (round loop; with the reference's Keccak table absorb), and the optimised "
+                        f"OpenMP variant on {threads} threads; a restatement, not the Rust/ark-ff binary (SURVEY.md 8d)",
         "cpu_model": cpu_model,
     }
+
+
+
+# ------------------------------------------------------------------------------------------------ proof checks
+def _fq(fn, a, b, np):
+    from zk_amd._lib import lib, u64p
+
+    out = np.empty(4, dtype=np.uint64)
+    a, b = np.ascontiguousarray(a, dtype=np.uint64), np.ascontiguousarray(b, dtype=np.uint64)
+    getattr(lib(), fn)(a.ctypes.data_as(u64p), b.ctypes.data_as(u64p), out.ctypes.data_as(u64p))
+    return out
+
+
+def check_mle_proof(zk_amd, np, poly, base, last):
+    """The verifier on the last timed proof, after the clock stopped (sumcheck/src/verifier.rs:29-62 partial_verify on a
+    transcript in the prover's starting state + :15-26 perform_oracle_check: the table evaluated at all challenges on the
+    device must equal g_last(r_last)).  Costs one more pass over the table."""
+    claim, coeffs, ch = last
+    t0 = time.perf_counter()
+    ok, final, vch = zk_amd.SumcheckVerifier.partial_verify(zk_amd.SumCheckProof(claim, coeffs), base.clone())
+    same_ch = bool(np.array_equal(vch, ch))
+    at_r = poly.evaluate(list(ch)).get_evaluation_points()[0]
+    oracle = bool(np.array_equal(at_r, final))
+    total = bool(np.array_equal(poly.evaluation_sum(), claim))
+    return {"verified": bool(ok and same_ch and oracle and total), "partial_verify": bool(ok), "challenges_match": same_ch,
+            "oracle_check": oracle, "claim_is_table_sum": total, "check_ms": (time.perf_counter() - t0) * 1e3,
+            "what": "SumcheckVerifier::partial_verify + perform_oracle_check (verifier.rs:15-62) on the last timed proof, outside the timed region"}
+
+
+def check_sum2x2_proof(zk_amd, np, tabs, base, claim, last):
+    """partial_verify (verifier.rs:29-62) on the last timed degree-2 proof, then the oracle check the caller of
+    partial_verify owes (gkr/src/verifier.rs:106-113 in the reference's only use): f(r)g(r) + h(r)k(r) from four device
+    evaluations must equal the final claim."""
+    proof, ch = last
+    t0 = time.perf_counter()
+    ok, final, vch = zk_amd.SumcheckVerifier.partial_verify(zk_amd.SumCheckProof(claim, proof.round_polys), base.clone())
+    same_ch = bool(np.array_equal(vch, ch))
+    e = [t.evaluate(list(ch)).get_evaluation_points()[0] for t in tabs]
+    at_r = _fq("zk_fq_add", _fq("zk_fq_mul", e[0], e[1], np), _fq("zk_fq_mul", e[2], e[3], np), np)
+    oracle = bool(np.array_equal(at_r, final))
+    return {"verified": bool(ok and same_ch and oracle), "partial_verify": bool(ok), "challenges_match": same_ch, "oracle_check": oracle,
+            "check_ms": (time.perf_counter() - t0) * 1e3,
+            "what": "SumcheckVerifier::partial_verify (verifier.rs:29-62) + f(r)g(r)+h(r)k(r) == final claim from four device evaluations, on the last "
+                    "timed proof, outside the timed region; the claim handed to the prover is g_0(0)+g_0(1) of an untimed first prove "
+                    "(generate_proof_for_partial_verify trusts its caller's claim, prover.rs:175-190)"}
 
 
 # ------------------------------------------------------------------------------------------------ one rank
@@ -219,9 +291,9 @@ def main():
     n_ranks = dist.get_world_size() if dist is not None else 1
     rccl = dist is not None and (result.get("transport") == "rccl" or (args.sharded_impl == "py" and dist.get_backend() == "nccl"))
     out = {
-        "metric": METRIC,
+        "metric": result.get("metric", METRIC),
         "value": result["elems_per_s"],
-        "unit": "field elems/s",
+        "unit": result.get("unit", "field elems/s"),
         "n_gpus": n_ranks,  # the world size that actually ran
         "steps": args.steps,
         "warmup": args.warmup,
@@ -238,11 +310,17 @@ def main():
         "transport": result.get("transport"),
         "rccl_ranks": n_ranks if rccl else 0,
     }
-    for k in ("absorb_ms", "inclusive_ms", "kernels", "kernel_forms", "int32_alu", "survey_8d_equivalent", "proof_check", "extra"):
+    if dist is not None and not rccl:
+        out["rccl_note"] = ("NO RCCL in this run: the ranks exchanged through a host all-gather over " + str(dist.get_backend()) +
+                            " (a rehearsal of the multi-GPU path, not an xGMI measurement)")
+    elif dist is not None and n_ranks == 1:
+        out["rccl_note"] = "RCCL communicator of ONE rank: the exchange path ran, nothing crossed xGMI"
+    for k in ("absorb_ms", "inclusive_ms", "kernels", "kernel_forms", "int32_alu", "survey_8d_equivalent", "proof_check", "sharded_impl_fallback",
+              "gkr", "extra"):
         if k in result:
             out[k] = result[k]
     if not args.no_cpu_baseline and n_ranks == 1 and args.workload == "mle":
-        out["cpu_baseline"] = cpu_baseline(args.cpu_log_n)
+        out["cpu_baseline"] = cpu_baseline(args.cpu_log_n, full_log=args.cpu_full_log)
     else:
         out["cpu_baseline"] = None
     emit(out)
@@ -269,8 +347,8 @@ def apply_knobs(args, ctx):
         ctx.set_deg2_fold3_fused(args.deg2_fold3_fused)
     if args.deg2_fused_below is not None:
         ctx.set_deg2_fused(args.deg2_fused_below)
-    if args.deg2_triple_from is not None:
-        ctx.set_deg2_triple(args.deg2_triple_from, args.deg2_triple_ring)
+    if args.deg2_triple_from is not None or args.deg2_triple_ring is not None:
+        ctx.set_deg2_triple(args.deg2_triple_from if args.deg2_triple_from is not None else 21, args.deg2_triple_ring or 4)
 
 
 def read_kernels(ctx, names=KERNEL_NAMES):
@@ -336,7 +414,7 @@ def int32_alu(ctx, kernels, forms):
     return alu
 
 
-def bench_single(args, ctx, zk_amd, np, workload, log_n, steps, warmup, absorb=False, want_alu=True):
+def bench_single(args, ctx, zk_amd, np, workload, log_n, steps, warmup, absorb=False, want_alu=True, check=True):
     import torch
 
     n = 1 << log_n
@@ -366,6 +444,10 @@ def bench_single(args, ctx, zk_amd, np, workload, log_n, steps, warmup, absorb=F
         def step():
             return zk_amd.SumcheckProver.generate_proof_for_partial_verify(claim, f, base.clone())
 
+        # the true claim = g_0(0) + g_0(1) = 2 c0 + c1 + c2 of an untimed prove (round 0 does not depend on the claim passed in)
+        c = step()[0].round_polys[0]
+        claim = _fq("zk_fq_add", _fq("zk_fq_add", c[0], c[0], np), _fq("zk_fq_add", c[1], c[2], np), np)
+
         kernel = "fold4_eval3" if args.deg2_rounds == 1 else "fold2x4_sum9"
         what = f"degree-2 sumcheck Sum[Prod[f,g],Prod[h,k]], 4 x 2^{log_n} entries, 1 GPU"
 
@@ -377,13 +459,17 @@ def bench_single(args, ctx, zk_amd, np, workload, log_n, steps, warmup, absorb=F
     ctx.synchronize()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    last = None
     for _ in range(steps):
-        step()
+        last = step()
     ctx.synchronize()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     ctx.prof_enable(False)
     ms_per_step = dt * 1e3 / steps
+    proof_check = None
+    if check and last is not None:
+        proof_check = check_mle_proof(zk_amd, np, poly, base, last) if workload == "mle" else check_sum2x2_proof(zk_amd, np, tabs, base, claim, last)
     forms = sorted(ctx.forms_used())
 
     kernels = read_kernels(ctx)
@@ -406,6 +492,8 @@ def bench_single(args, ctx, zk_amd, np, workload, log_n, steps, warmup, absorb=F
         "config": {"workload": what, "log_n": log_n, "field": "BN254 Fq",
                    "parallelism": "1 GPU", "transcript": "Keccak-256 on host, one challenge per round"},
     }
+    if proof_check is not None:
+        res["proof_check"] = proof_check
     if want_alu:
         res["int32_alu"] = int32_alu(ctx, kernels, forms)
     if workload == "mle":
@@ -436,48 +524,40 @@ def extra_workloads(args, ctx, zk_amd, np, torch):
     for log_n in sizes:
         r = bench_single(args, ctx, zk_amd, np, "mle", log_n, 3, 1, absorb=False, want_alu=False)
         sweep.append({"log_n": log_n, "prove_ms": r["ms_per_step"], "elems_per_s": r["elems_per_s"], "dominant_kernel": r["roofline"]["kernel"],
-                      "hbm_frac": r["roofline"]["frac"],
+                      "hbm_frac": r["roofline"]["frac"], "verified": r["proof_check"]["verified"],
                       "kernels": {k: {"avg_ms": v["avg_ms"], "launches_per_prove": v["launches"] / 3, "GBs": v["achieved_GBs"]} for k, v in r["kernels"].items()}})
         gc.collect()
     out["mle_sweep"] = sweep
     r = bench_single(args, ctx, zk_amd, np, "sum2x2", 26, 3, 1)
     out["sum2x2_log26"] = {"workload": r["config"]["workload"], "prove_ms": r["ms_per_step"], "entries_per_s": 4 * (1 << 26) / (r["ms_per_step"] * 1e-3),
                            "roofline": {k: r["roofline"][k] for k in ("kernel", "achieved", "peak", "unit", "frac")},
-                           "kernels": r["kernels"], "int32_alu": r.get("int32_alu")}
+                           "kernels": r["kernels"], "int32_alu": r.get("int32_alu"), "proof_check": r["proof_check"]}
     gc.collect()
     g = bench_gkr(args, ctx, zk_amd, np, 16, 20, 3, 1)
     out["gkr_config5"] = {k: g[k] for k in ("config", "prove_ms", "value", "unit", "layers_ms_total", "ms_per_round", "circuit_evaluate_ms",
-                                            "output_absorb_ms", "note")}
+                                            "output_absorb_ms", "host_other_ms", "proof_check", "note")}
     return out
 
 
-def bench_sharded(args, zk_amd, np, dist, rank, local_rank, world):
-    """One rank per GPU; the 2^log_n-entry table is sharded on the variables bound last.  Strong scaling by default (the
-    metric's 2^28 entries in total).  --sharded-impl lib (default): the loop and the exchange run inside libzkmi.so
-    (zk_sumcheck_prove_*_sharded: RCCL ncclAllGather on the context stream with the nccl backend, host all-gather through
-    torch.distributed otherwise); py: zk_amd/sharded.py over torch.distributed."""
+def setup_ranks(args, zk_amd, dist, local_rank):
+    """This rank's context and its communicator.  --sharded-impl lib: the library's own communicator (RCCL with the nccl backend, the
+    host all-gather callback otherwise).  zk_amd.sharded.comm_init votes before any id exchange, so the ranks fail together; if they
+    do (ZK_E_COMM: RCCL missing or refusing), every rank falls back to the torch.distributed loop of zk_amd/sharded.py and the line
+    says so (`sharded_impl_fallback`).  -> (ctx, use_lib, transport, fallback)"""
     import torch
 
     from zk_amd import sharded
 
-    if args.workload not in ("mle", "sum2x2"):
-        raise SystemExit("multi-GPU bench: --workload mle or sum2x2")
-    g = world.bit_length() - 1
-    if world != 1 << g:
-        raise SystemExit("world size must be a power of two")
-    log_total = args.log_n + (g if args.weak else 0)
-    n_local = 1 << (log_total - g)
     use_lib = args.sharded_impl == "lib"
     ctx = zk_amd.Context(local_rank) if use_lib else sharded.torch_stream_context(local_rank)
     apply_knobs(args, ctx)
-    fallback = None
+    fallback, transport = None, None
     if use_lib:
-        # the library's own communicator; if any rank cannot set it up (ZK_E_COMM: RCCL missing or refusing), every rank falls back to
-        # the torch.distributed loop of zk_amd/sharded.py together, and the line says so
         try:
             transport, err = sharded.comm_init(ctx, dist), None
         except Exception as e:  # noqa: BLE001 -- reported in the JSON line
             transport, err = None, repr(e)
+        # ncclCommInitRank itself can still fail on one rank only (after the vote inside comm_init): agree on the outcome
         flag = torch.tensor([0 if err else 1], dtype=torch.int32,
                             device=torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
@@ -490,6 +570,99 @@ def bench_sharded(args, zk_amd, np, dist, rank, local_rank, world):
             apply_knobs(args, ctx)
     if not use_lib:
         transport = "rccl" if dist.get_backend() == "nccl" else "host"
+    return ctx, use_lib, transport, fallback
+
+
+def digests_agree(np, torch, dist, arrays, dev) -> bool:
+    """every rank must hold the same bytes: MIN and MAX over ranks of a SHA-256 of them coincide"""
+    import hashlib
+
+    digest = hashlib.sha256(b"".join(np.ascontiguousarray(a).tobytes() for a in arrays)).digest()
+    dg = torch.frombuffer(bytearray(digest), dtype=torch.uint8).to(torch.int64).to(dev)
+    lo, hi = dg.clone(), dg.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    return bool(torch.equal(lo, hi))
+
+
+def bench_gkr_sharded(args, ctx, zk_amd, np, dist, rank, world, transport):
+    """GKR config 5 over the ranks (zk_gkr_prove_sharded; gkr/src/prover.rs:24-154): circuit and inputs replicated, every layer's
+    two sumcheck phases sharded on the low index bits.  The same circuit on every rank ("strong": total work fixed)."""
+    import torch
+
+    from zk_amd import sharded
+    from zk_amd.synthetic import gkr_layers
+
+    depth, k = args.gkr_depth, args.gkr_log_width
+    circuit = zk_amd.Circuit.from_arrays(gkr_layers(depth, k), ctx=ctx)
+    inputs = zk_amd.MultiLinearPolynomial.generate(SEED, 1 << k, ctx=ctx)
+    gather_log = args.gather_log if args.gather_log >= 0 else 0
+
+    def step(timing=False):
+        return zk_amd.GKRProver.generate_proof(circuit, zk_amd.Transcript(), inputs, timing=timing, sharded_gather_log=gather_log)
+
+    for _ in range(args.warmup):
+        step()
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    proof = None
+    for _ in range(args.steps):
+        proof = step()
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    dist.barrier()
+    dt = time.perf_counter() - t0
+    dev = torch.device("cuda", ctx.device_id) if dist.get_backend() == "nccl" else torch.device("cpu")
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    ms = float(tmax.item()) * 1e3 / args.steps
+    same = digests_agree(np, torch, dist, [proof.elements()], dev)
+    timed = step(timing=True)
+    verified = None
+    if rank == 0:   # the verifier on rank 0's last timed proof (gkr/src/verifier.rs:21-119), single GPU, outside the timed region
+        verified = bool(zk_amd.GKRVerifier.verify_proof(inputs, circuit, zk_amd.Transcript(), proof))
+    dist.barrier()
+    sharded.comm_destroy(ctx)
+    gates = depth << k
+    rounds = sum(p.round_polys.shape[0] for p in proof.sumcheck_proofs)
+    layers_ms = sum(timed.layer_ms[:depth])
+    return {
+        "elems_per_s": gates / (ms * 1e-3), "unit": "gates/s", "ms_per_step": ms,
+        "metric": "GKR prove ms + gates/s, layered circuit, wiring predicates built on device",
+        "roofline": None, "transport": transport, "sharded_impl_fallback": None,
+        "proof_check": {"all_ranks_identical": same, "verified": verified,
+                        "what": "SHA-256 of every rank's GKRProof elements agree; GKRVerifier::verify_proof accepts rank 0's last timed proof"},
+        "gkr": {"layers_ms_total": layers_ms, "ms_per_round": layers_ms / rounds, "circuit_evaluate_ms": timed.layer_ms[depth],
+                "output_absorb_ms": timed.layer_ms[depth + 1], "sumcheck_rounds": rounds,
+                "note": "latency-bound at this size (32 MiB of tables per layer): sharding adds an exchange per pass and removes no time (DESIGN.md 6); "
+                        "the line exists so an N-GPU box reports the GKR prove north_star asks for; the W_0 Keccak absorb is per rank and serial"},
+        "config": {"workload": f"GKR prove, depth {depth}, 2^{k} gates per layer, every layer's sumcheck sharded over {world} GPUs (circuit replicated)",
+                   "depth": depth, "log_width": k, "field": "BN254 Fq", "parallelism": f"layer tables sharded x{world}",
+                   "exchange": f"all-gather of nine sums per two rounds; tables of <= 2^{gather_log} entries per rank gathered and finished on every rank"},
+    }
+
+
+def bench_sharded(args, zk_amd, np, dist, rank, local_rank, world):
+    """One rank per GPU; the 2^log_n-entry table is sharded on the variables bound last.  Strong scaling by default (the
+    metric's 2^28 entries in total).  --sharded-impl lib (default): the loop and the exchange run inside libzkmi.so
+    (zk_sumcheck_prove_*_sharded: RCCL ncclAllGather on the context stream with the nccl backend, host all-gather through
+    torch.distributed otherwise); py: zk_amd/sharded.py over torch.distributed."""
+    import torch
+
+    from zk_amd import sharded
+
+    g = world.bit_length() - 1
+    if world != 1 << g:
+        raise SystemExit("world size must be a power of two")
+    ctx, use_lib, transport, fallback = setup_ranks(args, zk_amd, dist, local_rank)
+    if args.workload == "gkr":
+        if not use_lib:
+            raise SystemExit(f"multi-GPU GKR runs inside the library only (zk_gkr_prove_sharded); its communicator could not be set up: {fallback}")
+        return bench_gkr_sharded(args, ctx, zk_amd, np, dist, rank, world, transport)
+    log_total = args.log_n + (g if args.weak else 0)
+    n_local = 1 << (log_total - g)
     gather_log = args.gather_log if args.gather_log >= 0 else None
     base = zk_amd.Transcript()
     base.append(b"bench: table absorb skipped (sharded run; SURVEY.md H1)")
@@ -550,15 +723,7 @@ def bench_sharded(args, zk_amd, np, dist, rank, local_rank, world):
     dev = torch.device("cuda", ctx.device_id) if dist.get_backend() == "nccl" else torch.device("cpu")
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    # every rank must hold the same proof: compare a digest of (claim, round polys, challenges)
-    import hashlib
-
-    digest = hashlib.sha256(b"".join(np.ascontiguousarray(a).tobytes() for a in last)).digest()
-    dg = torch.frombuffer(bytearray(digest), dtype=torch.uint8).to(torch.int64).to(dev)
-    lo, hi = dg.clone(), dg.clone()
-    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
-    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-    same = bool(torch.equal(lo, hi))
+    same = digests_agree(np, torch, dist, last, dev)   # every rank must hold the same (claim, round polys, challenges)
     ms_per_step = float(tmax.item()) * 1e3 / args.steps
 
     kernels = read_kernels(ctx, names)
@@ -609,7 +774,12 @@ def bench_gkr(args, ctx, zk_amd, np, depth, k, steps, warmup):
     ctx.synchronize()
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) * 1e3 / steps
+    t0 = time.perf_counter()
     timed = step(timing=True)
+    timed_ms = (time.perf_counter() - t0) * 1e3
+    t0 = time.perf_counter()
+    verified = bool(zk_amd.GKRVerifier.verify_proof(inputs, circuit, zk_amd.Transcript(), proof))   # gkr/src/verifier.rs:21-119, outside the timed region
+    verify_ms = (time.perf_counter() - t0) * 1e3
     gates = depth << k
     rounds = sum(p.round_polys.shape[0] for p in proof.sumcheck_proofs)
     return {
@@ -622,6 +792,11 @@ def bench_gkr(args, ctx, zk_amd, np, depth, k, steps, warmup):
         "prove_ms": ms, "layer_ms": timed.layer_ms[:depth], "layers_ms_total": sum(timed.layer_ms[:depth]),
         "ms_per_round": sum(timed.layer_ms[:depth]) / rounds, "circuit_evaluate_ms": timed.layer_ms[depth],
         "output_absorb_ms": timed.layer_ms[depth + 1], "circuit_build_ms_host": build_ms,
+        # what the three timers inside zk_gkr_prove do not cover, on the SAME (timed) call: argument marshalling in Python, the proof
+        # arrays' allocation, the join of the output download thread, the final transcript bookkeeping
+        "host_other_ms": timed_ms - sum(timed.layer_ms[:depth + 2]), "timed_call_ms": timed_ms,
+        "proof_check": {"verified": verified, "verify_ms": verify_ms,
+                        "what": "GKRVerifier::verify_proof (zk_gkr_verify) accepts the last timed proof; outside the timed region"},
         "note": "prove_ms includes the reference's serial Keccak absorb of the 2^k-entry output layer (prover.rs:46, "
                 "output_absorb_ms); the layer sumchecks are latency-bound: 2*k_in sequential rounds per layer, each kernel + 96-byte D2H + host Keccak; tables are "
                 "2^k_in entries (32 MiB at k = 20), far below the HBM roofline regime",

@@ -189,7 +189,10 @@ int zk_shard_fold(zk_shard *s, int m, const uint64_t *r_mont, int m_next, void *
  * allocating routine: its scratch (per-workgroup partial sums, the weight tiles of a wide pass; 640 KiB) is a file-scope
  * __device__ array that every GPU the library runs on holds until the process ends.  len is limited to
  * 2^ZK_NOALLOC_MAX_LOG_LEN entries (ZK_E_TOO_LARGE beyond).  All calls on one GPU share that GPU's array: calls that
- * overlap on one GPU (two streams, two threads) race -- serialise them.  Pointers must be 16-byte aligned. */
+ * overlap on one GPU (two streams, two threads) race -- serialise them.  Pointers must be 16-byte aligned; the src, dst and
+ * sums ranges must not intersect (ZK_E_ARG: the kernels stream src while they store dst).  The FIRST call on a device takes
+ * the array's address with hipGetSymbolAddress, which is not capture-safe: before capturing a graph, make one call on that
+ * device outside the capture (or create any zk_ctx there: zk_ctx_create takes the address too). */
 #define ZK_NOALLOC_MAX_LOG_LEN 30
 int zk_fold_block_sums_noalloc(void *hip_stream, const void *src_dev, size_t len, int m, const uint64_t *r_mont,
                                void *dst_dev, int m_next, void *sums_dev_out);

@@ -7,13 +7,14 @@ fn main() {
     let out = PathBuf::from(env::var("OUT_DIR").unwrap());
     let src = PathBuf::from(env::var("CARGO_MANIFEST_DIR").unwrap()).join("../../zk_amd/csrc");
     let hipcc = env::var("HIPCC").unwrap_or_else(|_| "/opt/rocm/bin/hipcc".into());
-    let files = ["kernels.hip", "gkr_kernels.hip", "zkmi.cpp", "gkr.cpp", "sharded.cpp"];
+    // the same list as SRCS in zk_amd/csrc/Makefile (tests/test_abi_host.py fails when the two differ)
+    let files = ["kernels.hip", "deg2_kernels.hip", "gkr_kernels.hip", "zkmi.cpp", "gkr.cpp", "sharded.cpp"];
     let status = Command::new(&hipcc)
         .args(["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-shared"])
         .arg("-o")
         .arg(out.join("libzkmi.so"))
         .args(files.iter().map(|f| src.join(f)))
-        .args(["-ldl", "-Wl,-rpath,/opt/rocm/lib", "-Wl,--exclude-libs,ALL"])
+        .args(["-ldl", "-Wl,-rpath,/opt/rocm/lib", "-Wl,--exclude-libs,ALL", "-Wl,-z,defs"])
         .status()
         .expect("hipcc not found: set HIPCC");
     assert!(status.success(), "hipcc failed");

@@ -117,3 +117,22 @@ def test_rust_sys_crate_is_in_step_with_the_header():
     text = open(os.path.join(ROOT, "rust", "zkmi-sys", "src", "lib.rs")).read()
     assert sorted(re.findall(r"pub fn (zk_[a-z0-9_]+)\(", text)) == _declared_functions()
     assert text == gen.generate(open(os.path.join(ROOT, "include", "zkmi.h")).read()), "run python3 tools/gen_rust_sys.py"
+
+
+def test_rust_build_script_compiles_what_the_makefile_compiles():
+    """rust/zkmi-sys/build.rs is the build a Rust maintainer runs; it cannot be run here (no cargo).  Its source list and
+    compiler/linker flags must be those of zk_amd/csrc/Makefile, which IS exercised by build(): a translation unit added
+    to one and not the other fails here (and, with -z defs, at link time on both sides)."""
+    mk = open(os.path.join(ROOT, "zk_amd", "csrc", "Makefile")).read()
+    rs = open(os.path.join(ROOT, "rust", "zkmi-sys", "build.rs")).read()
+    mk_vars = {m.group(1): m.group(2).split() for m in re.finditer(r"^(\w+)\s*[:?]?=\s*(.*)$", mk, re.M)}
+    rs_files = re.findall(r'"([^"]+)"', re.search(r"let files = \[(.*?)\];", rs, re.S).group(1))
+    assert rs_files == mk_vars["SRCS"]
+    for f in rs_files:
+        assert os.path.exists(os.path.join(ROOT, "zk_amd", "csrc", f)), f
+    rs_args = [a for grp in re.findall(r"\.args\(\[(.*?)\]\)", rs, re.S) for a in re.findall(r'"([^"]+)"', grp)]
+    drop = {"-Wall", "-Wno-unused-result"}                       # diagnostics only
+    mk_flags = [f for f in mk_vars["CXXFLAGS"] + mk_vars["LDFLAGS"] if f not in drop]
+    assert sorted(a for a in rs_args if not a.startswith("--offload-arch") and a != "-shared") == sorted(mk_flags)
+    assert "--offload-arch=gfx950" in rs_args and "-Wl,-z,defs" in rs_args
+    assert mk_vars["ARCH"] == ["gfx950"]

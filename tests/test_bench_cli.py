@@ -62,3 +62,33 @@ def test_gpus_1_line_has_the_contract_keys():
     for k in ("fold_pass_frac", "sum9_frac"):
         if k in alu:
             assert 0 < alu[k] <= 1.0, (k, alu[k])
+
+
+@pytest.mark.gpu
+def test_gpus_2_gkr_line_through_the_sharded_layer_prover():
+    """bench.py --workload gkr --gpus N runs zk_gkr_prove_sharded on every rank (here: two gloo ranks sharing the GPU, a small
+    circuit), all ranks end with the same proof and rank 0's is accepted by the verifier."""
+    rc, lines, err = _run(["--gpus", "2", "--backend", "gloo", "--shared-device", "--workload", "gkr", "--gkr-depth", "3", "--gkr-log-width", "10",
+                           "--gather-log", "5", "--steps", "2", "--warmup", "1", "--no-extra"])
+    assert rc == 0 and len(lines) == 1, err[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["unit"] == "gates/s" and d["metric"].startswith("GKR prove")
+    assert d["proof_check"]["all_ranks_identical"] is True and d["proof_check"]["verified"] is True
+    assert d["rccl_ranks"] == 0 and "NO RCCL" in d["rccl_note"] and d["cpu_baseline"] is None
+    assert d["gkr"]["sumcheck_rounds"] == 3 * 20 and "sharded over 2 GPUs" in d["config"]["workload"]
+
+
+@pytest.mark.gpu
+def test_single_gpu_lines_carry_a_proof_check():
+    rc, lines, err = _run(["--gpus", "1", "--log-n", "18", "--steps", "2", "--warmup", "1", "--no-extra", "--no-absorb", "--no-cpu-baseline"])
+    assert rc == 0 and len(lines) == 1, err[-2000:]
+    pc = json.loads(lines[0])["proof_check"]
+    assert pc["verified"] is True and pc["oracle_check"] is True and pc["challenges_match"] is True and pc["claim_is_table_sum"] is True
+    rc, lines, err = _run(["--gpus", "1", "--workload", "sum2x2", "--log-n", "16", "--steps", "2", "--warmup", "1", "--no-extra", "--no-cpu-baseline"])
+    assert rc == 0 and len(lines) == 1, err[-2000:]
+    pc = json.loads(lines[0])["proof_check"]
+    assert pc["verified"] is True and pc["oracle_check"] is True
+    rc, lines, err = _run(["--gpus", "1", "--workload", "gkr", "--gkr-depth", "3", "--gkr-log-width", "10", "--steps", "2", "--warmup", "1"])
+    assert rc == 0 and len(lines) == 1, err[-2000:]
+    d = json.loads(lines[0])
+    assert d["proof_check"]["verified"] is True and "host_other_ms" in d

@@ -230,8 +230,30 @@ def test_gkr_config5_full_size():
     assert np.array_equal(ev[-1].get_evaluation_points(), proof.output_poly)
     vt = zk_amd.Transcript()
     assert GKRVerifier.verify_proof(inputs, circuit, vt, proof)
-    # the verifier appends the last layer's W evaluations (verifier.rs:101-104), the prover does not: replay that on a copy
-    assert vt.peek_digest() != b"" and len(vt.peek_digest()) == 32
+    # Transcript states.  (1) A host replay of the prover's stream (bytes(W_0), rho, then per layer
+    # [LE32(wb) LE32(wc), alpha, beta] + the sumcheck rounds through partial_verify) ends in the PROVER's final state.
+    # (2) The verifier appends the last layer's (W(r_b), W(r_c)) -- the INPUT polynomial at the two halves of the last
+    # challenges -- which the prover does not (gkr/src/verifier.rs:76-104 vs prover.rs:143-147): the prover's state
+    # plus those 64 bytes is the verifier's final state.
+    from zk_amd.gkr import _limbs_le32
+    from zk_amd.sumcheck import SumcheckVerifier
+
+    rt = zk_amd.Transcript()
+    rt.append(_limbs_le32(proof.output_poly, ctx))
+    rt.sample_n_challenges(k)
+    last_ch = None
+    for i, sp in enumerate(proof.sumcheck_proofs):
+        if i:
+            rt.append(_limbs_le32(np.stack(proof.w_polys_evals[i - 1]), ctx))
+            rt.sample_challenge(), rt.sample_challenge()
+        ok, _, last_ch = SumcheckVerifier.partial_verify(sp, rt)
+        assert ok
+    assert rt.peek_digest() == pt.peek_digest()
+    assert pt.peek_digest() != vt.peek_digest()
+    w_in = [inputs.evaluate(list(last_ch[:k])).get_evaluation_points()[0], inputs.evaluate(list(last_ch[k:])).get_evaluation_points()[0]]
+    pt2 = pt.clone()
+    pt2.append(_limbs_le32(np.stack(w_in), ctx))
+    assert pt2.peek_digest() == vt.peek_digest()
     # a second prove gives the same bytes (deterministic sums, fixed reduction order)
     again = GKRProver.generate_proof(circuit, zk_amd.Transcript(), inputs)
     assert np.array_equal(again.elements(), proof.elements())

@@ -87,3 +87,15 @@ def test_noalloc_fold_vs_oracle_and_errors():
     assert L.zk_fold_block_sums_noalloc(C.c_void_p(ctx.stream), p, 1 << 14, 9, r.ctypes.data_as(u64p), p, 0, None) == 8
     assert L.zk_fold_block_sums_noalloc(C.c_void_p(ctx.stream), p, 1 << 14, 4, r.ctypes.data_as(u64p), p, 2, None) == 8   # sums asked for, no buffer
     assert L.zk_fold_block_sums_noalloc(C.c_void_p(ctx.stream), None, 1 << 14, 4, r.ctypes.data_as(u64p), p, 0, None) == 8
+    # ranges that intersect are refused (the kernels stream src while storing dst): dst inside src, dst == src, sums inside dst
+    base = L.zk_mle_device_ptr(table.h)
+    other = zk_amd.MultiLinearPolynomial(t, ctx=ctx)
+    q = C.c_void_p(L.zk_mle_device_ptr(other.h))
+    rp = r.ctypes.data_as(u64p)
+    assert L.zk_fold_block_sums_noalloc(C.c_void_p(ctx.stream), p, 1 << 14, 4, rp, p, 0, None) == 8
+    assert L.zk_fold_block_sums_noalloc(C.c_void_p(ctx.stream), p, 1 << 14, 4, rp, C.c_void_p(base + (1 << 13) * 32), 0, None) == 8
+    assert L.zk_fold_block_sums_noalloc(C.c_void_p(ctx.stream), p, 1 << 14, 4, rp, q, 2, C.c_void_p(L.zk_mle_device_ptr(other.h) + 64)) == 8
+    assert L.zk_fold_block_sums_noalloc(C.c_void_p(ctx.stream), p, 1 << 14, 4, rp, q, 2, C.c_void_p(base + 32)) == 8
+    # dst directly behind src (adjacent, not intersecting) is fine
+    assert L.zk_fold_block_sums_noalloc(C.c_void_p(ctx.stream), p, 1 << 13, 4, rp, C.c_void_p(base + (1 << 13) * 32), 0, None) == 0
+    ctx.synchronize()

@@ -69,21 +69,21 @@ class Context:
         (the reference does not: gkr/src/verifier.rs:63-64).  Default off."""
         check(lib().zk_ctx_set_gkr_strict_claims(self.h, int(on)))
 
-    def set_deg2_mfma_sums(self, from_log: int = 16):
+    def set_deg2_mfma_sums(self, from_log: int = 22):
         """Degree-2 prover: nine-sum sweeps over >= 2^from_log quarter-entries run on the matrix cores (64 = never)."""
         check(lib().zk_ctx_set_deg2_mfma_sums(self.h, from_log))
 
     def set_deg2_fold3_fused(self, dma_slots: int = 4):
-        """Degree-2 prover, three-round passes followed by another: fold and the next cross sums in one sweep (0 = off; 4..6 = DMA slots per wave)."""
+        """Degree-2 prover, three-round passes followed by another: fold and the next cross sums in one sweep (0 = off; 3..5 = DMA slots per wave; library default 4)."""
         check(lib().zk_ctx_set_deg2_fold3_fused(self.h, dma_slots))
 
     def set_deg2_fused(self, below_log: int = 20):
         """Degree-2 prover: fold + nine sums of the result in one kernel while the folded tables have < 2^below_log entries (0 = never)."""
         check(lib().zk_ctx_set_deg2_fused(self.h, below_log))
 
-    def set_deg2_triple(self, from_log: int = 64, ring: int = 3):
+    def set_deg2_triple(self, from_log: int = 21, ring: int = 4):
         """Degree-2 prover: passes over tables of >= 2^from_log entries serve three rounds each (8 x 8 cross sums per term on the
-        matrix cores + one three-variable fold); 64 = never.  ring = LDS tiles of the sweep (3 or 4)."""
+        matrix cores + one three-variable fold); 64 = never.  ring = LDS tiles of the sweep (3 or 4).  Defaults = the library's (kernels.h DmaGates)."""
         check(lib().zk_ctx_set_deg2_triple(self.h, from_log, ring))
 
     def set_dma_gates(self, sums_from_log: int = 27, wide_stream_from_log: int = 22, fold2_from_log: int = 22):

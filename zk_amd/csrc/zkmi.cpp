@@ -607,6 +607,14 @@ int zk_fold_block_sums_noalloc(void* hip_stream, const void* src_dev, size_t len
     const unsigned ell = ilog2(len);
     if (m < 1 || m > zkk::kMaxFoldBatch || (unsigned)m > ell) return ZK_E_ARG;
     if (m_next < 0 || m_next > zkk::kMaxFoldBatch || (unsigned)(m + m_next) > ell || (m_next && !sums_dev_out)) return ZK_E_ARG;
+    { // the kernels stream src while they store dst (and the sums): ranges that intersect would silently yield garbage
+        const uintptr_t s0 = (uintptr_t)src_dev, s1 = s0 + len * kElem, d0 = (uintptr_t)dst_dev, d1 = d0 + (len >> m) * kElem;
+        if (s0 < d1 && d0 < s1) return ZK_E_ARG;
+        if (m_next) {
+            const uintptr_t q0 = (uintptr_t)sums_dev_out, q1 = q0 + ((size_t)kElem << m_next);
+            if ((s0 < q1 && q0 < s1) || (d0 < q1 && q0 < d1)) return ZK_E_ARG;
+        }
+    }
     void* base = nullptr; // this device's copy of the array (first call on a device: hipGetSymbolAddress; cached after that)
     if (zkk::static_scratch_ptr(&base) != hipSuccess) return ZK_E_HIP;
     void* partials = base;

@@ -504,14 +504,23 @@ def comm_init(ctx: Context, dist=None, group=None, transport: str | None = None)
     if transport is None:
         transport = "rccl" if backend in (None, "nccl") else "host"
     if transport == "rccl":
+        # Every rank probes RCCL locally first (zk_comm_unique_id resolves librccl.so.1 and makes an id; only rank 0's is used) and
+        # the ranks vote BEFORE any id exchange: a rank that cannot load RCCL must not leave its peers waiting in a broadcast or
+        # inside ncclCommInitRank's rendezvous.  All ranks raise together or go on together.
         ident = np.zeros(128, dtype=np.uint8)
-        if rank == 0:
-            check(lib().zk_comm_unique_id(ident.ctypes.data_as(C.POINTER(C.c_uint8))), ctx.h)
+        rc = lib().zk_comm_unique_id(ident.ctypes.data_as(C.POINTER(C.c_uint8)))
         if world > 1:
             dev = torch.device("cuda", ctx.device_id) if backend == "nccl" else torch.device("cpu")
+            flag = torch.tensor([1 if rc == 0 else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+            if int(flag.item()) == 0:
+                check(rc, ctx.h)       # this rank's own failure, with the library's text
+                raise RuntimeError("zk_comm_unique_id failed on another rank: no RCCL communicator on any rank")
             t = torch.from_numpy(ident).to(dev)
             dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
             ident = t.cpu().numpy()
+        else:
+            check(rc, ctx.h)
         check(lib().zk_comm_init_rccl(ctx.h, ident.ctypes.data_as(C.POINTER(C.c_uint8)), rank, world), ctx.h)
     elif transport == "host":
         if backend == "nccl":
