@@ -79,18 +79,26 @@ def parse(argv=None):
 def launch_ranks(args) -> int:
     """`--gpus N` without a launcher: start N fresh ranks (one per GPU) BEFORE this process touches a GPU, pass rank 0's
     line through, and refuse to print a line whose n_gpus is not the world size that ran."""
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    proc = subprocess.run(cmd, stdout=subprocess.PIPE, env=env)
-    line = None
-    for raw in proc.stdout.decode(errors="replace").splitlines():
-        if raw.startswith("{"):
-            line = raw
+    for attempt in range(3):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+        err = proc.stderr.decode(errors="replace")
+        sys.stderr.write(err)
+        line = None
+        for raw in proc.stdout.decode(errors="replace").splitlines():
+            if raw.startswith("{"):
+                line = raw
+        # the port was free when picked and taken before the ranks bound it: nothing ran, pick another (no GPU work is repeated)
+        if proc.returncode != 0 and line is None and ("EADDRINUSE" in err or "address already in use" in err.lower()) and attempt < 2:
+            sys.stderr.write(f"bench.py: rendezvous port {port} was taken before the ranks bound it; trying another\n")
+            continue
+        break
     if proc.returncode != 0 or line is None:
         sys.stderr.write(f"bench.py: the {args.gpus}-rank run failed (exit {proc.returncode}); no result line\n")
         return proc.returncode or 1

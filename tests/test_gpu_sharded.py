@@ -22,18 +22,19 @@ SEED = 0x5EED0000
 
 
 def _free_port():
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        return s.getsockname()[1]
+    """A rendezvous for one spawn: a FileStore URL, not a TCP port -- a port picked here can be taken by another process before
+    the ranks bind it (seen once on a GPU box: EADDRINUSE in TCPStore), a fresh file name cannot."""
+    import tempfile
+    import uuid
+    return "file://" + os.path.join(tempfile.gettempdir(), f"zk_rdv_{os.getpid()}_{uuid.uuid4().hex}")
 
 
 def _worker(rank, world, port, backend, log_n, fold_batch, generated, outdir, gather_log=None):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.cuda.set_device(0)
     if backend == "nccl":
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+        dist.init_process_group("nccl", init_method=port, rank=rank, world_size=world, device_id=torch.device("cuda", 0))
     else:
-        dist.init_process_group(backend, rank=rank, world_size=world)
+        dist.init_process_group(backend, init_method=port, rank=rank, world_size=world)
     try:
         ctx = sharded.torch_stream_context(0)
         if fold_batch is None:  # the library's own schedule, with the wide passes switched on for tables this small
@@ -131,12 +132,11 @@ def test_device_shard_steps_match_oracle():
 
 # ---------------------------------------------------------------- degree-2 branch, sharded
 def _worker4(rank, world, port, backend, log_n, gather_log, outdir):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.cuda.set_device(0)
     if backend == "nccl":
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+        dist.init_process_group("nccl", init_method=port, rank=rank, world_size=world, device_id=torch.device("cuda", 0))
     else:
-        dist.init_process_group(backend, rank=rank, world_size=world)
+        dist.init_process_group(backend, init_method=port, rank=rank, world_size=world)
     try:
         ctx = sharded.torch_stream_context(0)
         n = 1 << log_n
@@ -196,12 +196,11 @@ def test_sharded_loops_on_a_context_with_its_own_stream(gather_log):
 
 # ---------------------------------------------------------------- the loops inside the library (sharded.cpp)
 def _worker_lib(rank, world, port, backend, transport, log_n, gather_log, absorb, knobs, outdir):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.cuda.set_device(0)
     if backend == "nccl":
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+        dist.init_process_group("nccl", init_method=port, rank=rank, world_size=world, device_id=torch.device("cuda", 0))
     else:
-        dist.init_process_group(backend, rank=rank, world_size=world)
+        dist.init_process_group(backend, init_method=port, rank=rank, world_size=world)
     try:
         ctx = zk_amd.Context(0)  # its own stream: the library orders its kernels, copies and collectives itself
         if knobs is True:
@@ -304,9 +303,8 @@ def _gkr_case(case):
 
 
 def _worker_gkr(rank, world, port, case, gather_log, outdir):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method=port, rank=rank, world_size=world)
     try:
         from test_gpu_gkr import mk, proof_bytes
         ctx = zk_amd.Context(0)

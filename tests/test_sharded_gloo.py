@@ -64,14 +64,15 @@ class OracleShard:
 
 
 def _free_port():
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        return s.getsockname()[1]
+    """A rendezvous for one spawn: a FileStore URL, not a TCP port -- a port picked here can be taken by another process before
+    the ranks bind it (seen once on a GPU box: EADDRINUSE in TCPStore), a fresh file name cannot."""
+    import tempfile
+    import uuid
+    return "file://" + os.path.join(tempfile.gettempdir(), f"zk_rdv_{os.getpid()}_{uuid.uuid4().hex}")
 
 
 def _worker(rank, world, port, log_n, fold_batch, gather_log, outdir):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method=port, rank=rank, world_size=world)
     try:
         n = 1 << log_n
         table = O.gen_table(SEED, 0, n)
@@ -201,8 +202,7 @@ class OracleShard4:
 
 
 def _worker4(rank, world, port, log_n, gather_log, outdir):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method=port, rank=rank, world_size=world)
     try:
         n = 1 << log_n
         tabs = [O.gen_table(SEED + 10 + k, 0, n) for k in range(4)]
