@@ -737,6 +737,13 @@ void launch_eq_weights28(const uint64_t* r, int m, const uint64_t two24[4], void
     ch.two24 = to_fq(two24);
     hipLaunchKernelGGL(k_eq_weights28, dim3(1), dim3(kThreads), 0, st, ch, m, (u32*)wbuf);
 }
+// the weight tiles of the matrix-core fold (k_eq_weights_mfma) for m challenges into wbuf: 2^(m-1) x kMfmaTileWords u32
+void launch_eq_weights_mfma(const uint64_t* r, int m, const uint64_t two24[4], void* wbuf, hipStream_t st) {
+    ChalWide ch;
+    for (int l = 0; l < kMaxFoldBatch; ++l) ch.r[l] = l < m ? to_fq(r + 4 * l) : fq{};
+    ch.two24 = to_fq(two24);
+    hipLaunchKernelGGL(k_eq_weights_mfma, dim3(1u << (m - 1)), dim3(kThreads), 0, st, ch, m, (u32*)wbuf);
+}
 int launch_block_sums(const void* T, size_t L, int log_ob, void* partials, void* out, hipStream_t st, const DmaGates& gates) {
     const size_t Lb0 = L >> log_ob;
     // large tables: LDS-DMA stream with the nt policy, 6.7 vs 6.1 TB/s at 2^28 entries; it wins from 2^27 entries

@@ -203,5 +203,10 @@ struct Tab4w { fq* t[4]; };
 
 // eq weights of a wide pass into wbuf (k_eq_weights28, kernels.hip): wbuf[b * 10 + j] = limb j of eq(r, b) * 2^280 mod p, b < 2^m
 void launch_eq_weights28(const uint64_t* r, int m, const uint64_t two24[4], void* wbuf, hipStream_t st);
+// the same weights as signed radix-256 digit tiles for the matrix-core folds (k_eq_weights_mfma, kernels.hip):
+// wbuf[((bp * 4 + mt) * 64 + lane) * 4 + u], bp < 2^(m-1); every output of such a fold carries the constant kMfmaFoldFix
+void launch_eq_weights_mfma(const uint64_t* r, int m, const uint64_t two24[4], void* wbuf, hipStream_t st);
+// 128 (2^256 - 1)/255 - 2^27 ((2^512 - 1)/255) 2^-280 mod p (kernels.hip, "the wide pass on the matrix cores")
+#define ZK_MFMA_FOLD_FIX {{0xe5f7fc63u, 0xf613786fu, 0x795bc6d2u, 0xbe62fc84u, 0x799d7fdeu, 0xed6bec43u, 0x8c88f1adu, 0x164bcf99u}}
 
 } // namespace zkk
