@@ -64,7 +64,7 @@ def parse(argv=None):
     ap.add_argument("--deg2-mfma-from", type=int, default=None, help="degree-2 prover: nine sums on the matrix cores from 2^k quarter-entries (64 = never)")
     ap.add_argument("--deg2-triple-from", type=int, default=None, help="degree-2 prover: three rounds per pass on tables of >= 2^k entries (64 = never)")
     ap.add_argument("--deg2-fused-below", type=int, default=None, help="degree-2 prover: fold + nine sums in one kernel for folded tables below 2^k entries (0 = never)")
-    ap.add_argument("--deg2-fold3-fused", type=int, default=None, help="degree-2 prover: three-variable fold fused with the next cross sums (0 = off, 3..5 = DMA slots per wave)")
+    ap.add_argument("--deg2-fold3-fused", type=int, default=None, help="degree-2 prover: three-variable fold fused with the next cross sums (0 = off, 8 = fold on the matrix cores (default), 3..5 = DMA slots per wave of the VALU-fold form)")
     ap.add_argument("--deg2-triple-ring", type=int, default=None, help="LDS tiles of the three-round sweep (3 or 4; default: the library's, 4)")
     ap.add_argument("--weak", action="store_true", help="multi-GPU: 2^log_n entries PER GPU instead of in total")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend of the ranks' rendezvous (nccl = RCCL; gloo for rehearsals)")

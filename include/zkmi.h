@@ -398,8 +398,10 @@ int zk_ctx_set_deg2_mfma_sums(zk_ctx *ctx, int from_log);
  * ring = 3 or 4 LDS tiles in the sweep.  An execution schedule: proof bytes do not depend on it. */
 int zk_ctx_set_deg2_triple(zk_ctx *ctx, int from_log, int ring);
 /* Three-round passes whose successor serves three rounds too: the three-variable fold and the next level's cross sums are ONE sweep
- * (k_fold3_cross64: the folded rows go to HBM and into the LDS tile of the matrix stage, so the folded tables are not re-read).
- * dma_slots = LDS-DMA slots per wave, 3..5; 0 = separate fold and sums sweeps.  Proof bytes do not depend on it. */
+ * (the folded rows go to HBM and into the LDS tile of the matrix stage, so the folded tables are not re-read).
+ * dma_slots = 8 (default): the fold's contraction runs on the matrix cores as well (k_fold3_cross64_mfma; 12..14 = the same with a
+ * ring of 2..4 steps per wave); 3..5: the vector-ALU fold (k_fold3_cross64) with that many LDS-DMA slots per wave; 0 = separate fold
+ * and sums sweeps.  Proof bytes do not depend on it. */
 int zk_ctx_set_deg2_fold3_fused(zk_ctx *ctx, int dma_slots);
 /* Degree-2 prover, two rounds per pass: while the folded tables have fewer than 2^below_log entries (0 = never) the two-variable fold
  * (prover.rs:131-139, twice) and the nine sums of its result (the next two rounds' prover.rs:89-107) are one kernel -- GKR layer

@@ -629,11 +629,12 @@ def test_sum2x2_three_rounds_per_pass_vs_oracle(log_n, ring):
         assert np.array_equal(t.get_evaluation_points(), src)      # the factor tables are left unmodified
 
 
-@pytest.mark.parametrize("slots", [3, 4, 5])
+@pytest.mark.parametrize("slots", [3, 4, 5, 8])
 @pytest.mark.parametrize("log_n", [12, 13, 15, 16, 18])
 def test_sum2x2_fold_fused_with_next_cross_sums_vs_oracle(log_n, slots):
-    """k_fold3_cross64: the three-variable fold and the next level's cross sums in one sweep (tables of >= 2^12 entries have a
-    successor pass of whole 64-entry eighths).  Same proof bytes as the oracle."""
+    """k_fold3_cross64 (slots 3..5) / k_fold3_cross64_mfma (slots = 8: the fold on the matrix cores too): the three-variable fold and
+    the next level's cross sums in one sweep (tables of >= 2^12 entries have a successor pass of whole 64-entry eighths).  Same proof
+    bytes as the oracle."""
     c = zk_amd.Context(0)
     c.set_deg2_triple(0, 4)
     c.set_deg2_fold3_fused(slots)
@@ -645,7 +646,7 @@ def test_sum2x2_fold_fused_with_next_cross_sums_vs_oracle(log_n, slots):
     c.forms_used()
     proof, pts = zk_amd.SumcheckProver.generate_proof_for_partial_verify(O.fq1(5), f, tr)
     forms = c.forms_used()
-    assert "fold3_cross64" in forms and "cross64" in forms, forms
+    assert ("fold3_cross64_mfma" if slots == 8 else "fold3_cross64") in forms and "cross64" in forms, forms
     ocoeffs, och = O.sumcheck_prove_sum([[tabs[0], tabs[1]], [tabs[2], tabs[3]]], O.fq1(5), otr)
     assert np.array_equal(proof.round_polys, ocoeffs), log_n
     assert np.array_equal(pts, och) and tr.peek_digest() == otr.peek_digest()

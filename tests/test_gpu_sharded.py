@@ -206,9 +206,9 @@ def _worker_lib(rank, world, port, backend, transport, log_n, gather_log, absorb
         if knobs is True:
             ctx.set_wide_fold(8, 2, 10)
             ctx.set_dma_gates(0, 0, 0)
-        elif knobs in ("triple", "triple_unfused"):  # degree 2: three rounds per exchange on these small tables
+        elif knobs in ("triple", "triple_unfused", "triple_mfma"):  # degree 2: three rounds per exchange on these small tables
             ctx.set_deg2_triple(0, 4)
-            ctx.set_deg2_fold3_fused(4 if knobs == "triple" else 0)
+            ctx.set_deg2_fold3_fused(8 if knobs == "triple_mfma" else 4 if knobs == "triple" else 0)
         assert sharded.comm_init(ctx, dist, None, transport) == transport
         assert zk_amd.lib().zk_comm_rank(ctx.h) == rank and zk_amd.lib().zk_comm_world(ctx.h) == world
         n = 1 << log_n
@@ -224,9 +224,9 @@ def _worker_lib(rank, world, port, backend, transport, log_n, gather_log, absorb
         tr2.append(b"degree-2 sharded")
         ctx.forms_used()
         c2, ch2 = sharded.prove_sum2x2_sharded(tabs, tr2, None, gather_log)
-        if knobs in ("triple", "triple_unfused") and gather_log is not None and n // world >= 512 and (n // world).bit_length() - 1 > max(gather_log, 1):
+        if knobs in ("triple", "triple_unfused", "triple_mfma") and gather_log is not None and n // world >= 512 and (n // world).bit_length() - 1 > max(gather_log, 1):
             forms = ctx.forms_used()
-            assert "cross64" in forms and ("fold3_cross64" in forms or "fold3_dma" in forms), forms
+            assert "cross64" in forms and ("fold3_cross64" in forms or "fold3_cross64_mfma" in forms or "fold3_dma" in forms), forms
         np.savez(os.path.join(outdir, f"L{rank}.npz"), claim=claim, coeffs=coeffs, ch=ch, c2=c2, ch2=ch2, dg=np.frombuffer(tr2.peek_digest(), dtype=np.uint8))
         sharded.comm_destroy(ctx)
         assert zk_amd.lib().zk_comm_world(ctx.h) == 0
@@ -253,7 +253,7 @@ def _check_lib(tmp_path, world, log_n):
 @pytest.mark.parametrize("world,log_n,gather_log,absorb,knobs", [
     (2, 14, 13, True, False), (4, 13, 6, False, False), (8, 12, None, True, False), (2, 3, None, False, False), (2, 15, 9, False, True),
     (4, 14, None, False, True), (2, 12, 1, False, False), (8, 9, 13, True, False), (2, 1, None, False, False), (4, 2, 0, False, False),
-    (2, 15, 3, False, "triple"), (4, 15, 6, False, "triple"), (2, 14, 1, False, "triple_unfused"), (8, 16, 4, False, "triple"), (2, 16, 9, False, "triple_unfused")])
+    (2, 15, 3, False, "triple"), (2, 15, 3, False, "triple_mfma"), (4, 16, 6, False, "triple_mfma"), (4, 15, 6, False, "triple"), (2, 14, 1, False, "triple_unfused"), (8, 16, 4, False, "triple"), (2, 16, 9, False, "triple_unfused")])
 def test_library_sharded_provers_ranks_on_one_gpu(tmp_path, world, log_n, gather_log, absorb, knobs):
     """zk_sumcheck_prove_mle_sharded / _sum2x2_sharded (the loops in C++, exchange through the library's host all-gather
     callback, here over gloo: RCCL refuses several ranks on one GPU) against the oracle's proof of the unsharded table."""

@@ -9,7 +9,7 @@ KERNELS = {"block_sums": 0, "multifold": 1, "fold": 2, "eval3": 3, "fold4_eval3"
 
 
 FORMS = ["sums_dma", "sums_reg", "wide_dma", "wide_dma_stream", "wide_reg", "wide_lds", "coop", "fold2_dma", "fold2_reg", "sum9_lazy", "sum9",
-         "fold2_sum9", "wide_mfma", "sum9_mfma", "cross64", "fold3_dma", "fold3_cross64"]
+         "fold2_sum9", "wide_mfma", "sum9_mfma", "cross64", "fold3_dma", "fold3_cross64", "fold3_cross64_mfma"]
 
 
 class Context:
@@ -73,8 +73,8 @@ class Context:
         """Degree-2 prover: nine-sum sweeps over >= 2^from_log quarter-entries run on the matrix cores (64 = never)."""
         check(lib().zk_ctx_set_deg2_mfma_sums(self.h, from_log))
 
-    def set_deg2_fold3_fused(self, dma_slots: int = 4):
-        """Degree-2 prover, three-round passes followed by another: fold and the next cross sums in one sweep (0 = off; 3..5 = DMA slots per wave; library default 4)."""
+    def set_deg2_fold3_fused(self, dma_slots: int = 8):
+        """Degree-2 prover, three-round passes followed by another: fold and the next cross sums in one sweep (0 = off; 3..5 = DMA slots per wave of the VALU-fold form; 8 = the fold on the matrix cores too)."""
         check(lib().zk_ctx_set_deg2_fold3_fused(self.h, dma_slots))
 
     def set_deg2_fused(self, below_log: int = 20):

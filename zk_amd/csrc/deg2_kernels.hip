@@ -762,6 +762,366 @@ __global__ void __launch_bounds__(512) k_fold3_cross64(Tab4 S, Tab4w Dst, size_t
     }
 }
 
+// ---- the same sweep with the FOLD on the matrix cores too (round 3) ---------------------------------------------------------------
+// k_fold3_cross64 runs its fold half as radix-2^28 v_mad_u64_u32 chains (81 per source entry) beside the matrix stage; at its two
+// waves per SIMD that arithmetic is not hidden (0.55 of the HBM peak, 5.7 x 10^8 vector instructions per 8.6 GB launch).  Here the fold is
+// the byte-cut contraction of k_multifold_wide_mfma (kernels.hip): an output row of 64 entries is  sum over 4 b-pairs of
+// [64 product columns x 64 K] x [64 K x 64 outputs]  with K = (row of the pair, byte), 16 v_mfma_i32_16x16x64_i8 per b-pair, the
+// weights' signed-digit Toeplitz tiles (k_eq_weights_mfma, m = 3: 16 KiB) resident in LDS for the whole kernel, one radix-2^28
+// reduction per output and the same constant kfix.
+// Registers decide the shape: the 64 cross-sum blocks of a term are 128 accumulator registers per lane over eight waves, the fold's
+// columns 64 more, and at 256 registers per wave (two waves per SIMD) that spills into the DMA waits.  So a workgroup is FOUR waves, one
+// per SIMD with the whole 512-register file: wave w keeps the 4 x 4 block C[4 (w & 1) + i][4 (w >> 1) + k] (256 registers: exactly the
+// accumulator half of the file) and folds tile rows 4w .. 4w + 3.  A step is one b-pair of one row: 2 source rows (4 KiB, four LDS-DMA
+// instructions) through the wave's ring of NP steps, refilled as soon as the operands are in registers.  The 64 columns of an output come
+// out of the matrix cores spread over the four 16-lane rows of the wave; v_permlane32_swap / v_permlane16_swap transpose them in
+// registers (32 swaps per output row; no LDS round trip).  The folded row goes to HBM and, as byte ^ 0x80, into the tile: the matrix
+// stage takes its operands as they are.  Plain sums A_e, B_e' per lane in LDS (one 256-bit addition per folded entry).
+// LDS: tile 32 KiB + weights 16 KiB + rings 16 NP KiB + plain sums 36 KiB (NP <= 4: 148 KiB), one workgroup per CU.  Same partials
+// layout as k_cross64_mfma.
+typedef u32 u32x2 __attribute__((ext_vector_type(2)));
+// P[o4][k]: on entry this 16-lane row's words for output tile o4; on exit P[g'][k] = the words row g' held for THIS row's tile
+template <int NW>
+__device__ __forceinline__ void rows_transpose4(u32 (&P)[4][NW]) {
+#pragma unroll
+    for (int k = 0; k < NW; ++k) { // lanes 32..63 of the first operand <-> lanes 0..31 of the second
+        u32x2 r = __builtin_amdgcn_permlane32_swap(P[0][k], P[2][k], false, false);
+        P[0][k] = r[0];
+        P[2][k] = r[1];
+        r = __builtin_amdgcn_permlane32_swap(P[1][k], P[3][k], false, false);
+        P[1][k] = r[0];
+        P[3][k] = r[1];
+    }
+#pragma unroll
+    for (int k = 0; k < NW; ++k) { // odd rows of the first operand <-> even rows of the second
+        u32x2 r = __builtin_amdgcn_permlane16_swap(P[0][k], P[1][k], false, false);
+        P[0][k] = r[0];
+        P[1][k] = r[1];
+        r = __builtin_amdgcn_permlane16_swap(P[2][k], P[3][k], false, false);
+        P[2][k] = r[0];
+        P[3][k] = r[1];
+    }
+}
+// the 64 x 64 column block of one output row (fa[mt][o4]: SIGNED columns 16 mt + 4 g + r of output (o4, n), lane = 16 g + n, each within
+// +-2^27) -> the field element of output `lane`: sum_k 256^k (column_k + 2^27) * 2^-280 mod p + kfix (kfix carries -2^27 per column).
+// c1 = 1, c8 = 2^8, c16 = 2^16, c24 = 2^24 as values the compiler cannot see through: the pack then is four v_mad_i64_i32 per word
+// (a constant power of two would be turned into 64-bit shifts and additions, three times the instructions)
+__device__ __forceinline__ fq mfma_fold_finish(const v4i (&fa)[4][4], const fq& kfix, int c1, int c8, int c16, int c24) {
+    u32 P[4][8];
+    const long long bias = (1ll << 27) + (1ll << 35) + (1ll << 43) + (1ll << 51); // 2^27 at each of the word's four columns
+#pragma unroll
+    for (int o4 = 0; o4 < 4; ++o4)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) { // four consecutive columns -> one 64-bit word (below 2^53)
+            const v4i a = fa[mt][o4];
+            const long long x = (long long)a[0] * c1 + ((long long)a[1] * c8 + ((long long)a[2] * c16 + ((long long)a[3] * c24 + bias)));
+            P[o4][2 * mt] = (u32)(u64)x;
+            P[o4][2 * mt + 1] = (u32)((u64)x >> 32);
+        }
+    rows_transpose4<8>(P);
+    // word 4 mt + g' (weight 2^(32 (4 mt + g'))) of this lane's output came from row g'
+    u32 v[18];
+    u64 cy = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int mt = k >> 2, gp = k & 3;
+        cy += P[gp][2 * mt];
+        v[k] = (u32)cy;
+        cy = (cy >> 32) + P[gp][2 * mt + 1];
+    }
+    v[16] = (u32)cy;
+    v[17] = (u32)(cy >> 32);
+    u64 a28[20];
+#pragma unroll
+    for (int k = 0; k < 20; ++k) { // bits [28 k, 28 k + 28): a funnel shift over two adjacent words (wd + 1 <= 17 for every k)
+        const int bit = 28 * k, wd = bit >> 5, sh = bit & 31;
+        a28[k] = __builtin_amdgcn_alignbit(v[wd + 1], v[wd], sh) & FQ28_MASK;
+    }
+    return fq_add(fq28_redc(a28), kfix);
+}
+
+template <bool BIG, int NP>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+k_fold3_cross64_mfma(Tab4 S, Tab4w Dst, size_t outlen, const u32x4* __restrict__ wtiles, fq kfix, fq* __restrict__ partials) {
+    constexpr int NE = 8;
+    __shared__ u32x4 tile[2 * NE][128];
+    __shared__ u32x4 wl[4][4][64];
+    __shared__ u32x4 ring[4][NP][2][128];
+    __shared__ u32 pls[4][4][9][64]; // per lane: plain sums of the folded rows 4w .. 4w + 3 (36 KiB: kept out of the registers)
+    static_assert(NP >= 2 && NP <= 4, "LDS: 32 + 16 + 16 NP + 36 KiB");
+    const int term = blockIdx.y, lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int fi = w & 1, gi = w >> 1; // cross products: F rows 4 fi .. + 3 against G rows 4 gi .. + 3
+    const int g = lane >> 4, n = lane & 15;
+    const size_t qn = outlen >> 3; // the next level's eighth
+    const size_t stride = (size_t)gridDim.x * 64, base0 = (size_t)blockIdx.x * 64;
+    const int nt = base0 < qn ? (int)((qn - base0 + stride - 1) / stride) : 0;
+    const int nsteps = nt * 16; // this wave's steps: s = 16 t + 4 rq + bp
+    const fq* __restrict__ src = S.t[2 * term + (w >> 1)]; // rows 4w .. 4w + 3 belong to one factor table
+    fq* __restrict__ dst = Dst.t[2 * term + (w >> 1)];
+    const size_t e0 = (size_t)((4 * w) & 7);
+    { // the weight tiles: 1024 x 16 B, once per workgroup
+        u32x4* wflat = &wl[0][0][0];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) wflat[threadIdx.x + 256 * k] = wtiles[threadIdx.x + 256 * k];
+    }
+    __syncthreads();
+    const char* lanep = reinterpret_cast<const char*>(src) + (size_t)lane * 16; // this lane's 16 bytes of a row's first KiB
+    auto issue = [&](int s, int slot) { // source rows 2 bp, 2 bp + 1 of step s
+        const int t = s >> 4, rq = (s >> 2) & 3, bp = s & 3;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            // The row's offset is wave-uniform (scalar registers); the asm keeps the compiler from hoisting the 32 row addresses of a tile
+            // out of the loop as 64-bit pairs in vector registers (64 registers this kernel does not have): one add per row instead
+            size_t off = ((size_t)(2 * bp + r) * outlen + (e0 + (size_t)rq) * qn + base0 + (size_t)t * stride) * sizeof(fq);
+            asm volatile("" : "+s"(off));
+            const char* p = lanep + off;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
+                                             (__attribute__((address_space(3))) void*)&ring[w][slot][r][0], 16, 0, 2);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p + 1024),
+                                             (__attribute__((address_space(3))) void*)&ring[w][slot][r][64], 16, 0, 2);
+        }
+    };
+    v16i acc[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc[e][k] = 0;
+    int c1 = 1, c8 = 1 << 8, c16 = 1 << 16, c24 = 1 << 24; // mfma_fold_finish: multipliers the compiler must not fold into shifts
+    asm volatile("" : "+s"(c1), "+s"(c8), "+s"(c16), "+s"(c24));
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int k = 0; k < 9; ++k) pls[w][i][k][lane] = 0;
+    const int qq = (lane >> 1) & 7, pp = lane & 1; // transposed-read address inside a row: see k_sum16_mfma
+    const u32 tr_off = (u32)((16 * (g >> 1) + qq) * 32 + 16 * (g & 1) + 8 * pp);
+    auto matrix_stage = [&]() {
+        const u32 tb = (u32)(uintptr_t)&tile[0][0];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) { // 32 eighth-indices per step; the bytes in the tile are already byte - 128
+            const u32 a0 = tb + (u32)(4 * fi) * 2048u + (u32)ks * 1024u + tr_off;
+            const u32 b0 = tb + (u32)(NE + 4 * gi) * 2048u + (u32)ks * 1024u + tr_off;
+            u64 fa[4][2], gb[4][2];
+            asm volatile(
+                "ds_read_b64_tr_b8 %0, %16\n\t"
+                "ds_read_b64_tr_b8 %1, %16 offset:256\n\t"
+                "ds_read_b64_tr_b8 %2, %16 offset:2048\n\t"
+                "ds_read_b64_tr_b8 %3, %16 offset:2304\n\t"
+                "ds_read_b64_tr_b8 %4, %16 offset:4096\n\t"
+                "ds_read_b64_tr_b8 %5, %16 offset:4352\n\t"
+                "ds_read_b64_tr_b8 %6, %16 offset:6144\n\t"
+                "ds_read_b64_tr_b8 %7, %16 offset:6400\n\t"
+                "ds_read_b64_tr_b8 %8, %17\n\t"
+                "ds_read_b64_tr_b8 %9, %17 offset:256\n\t"
+                "ds_read_b64_tr_b8 %10, %17 offset:2048\n\t"
+                "ds_read_b64_tr_b8 %11, %17 offset:2304\n\t"
+                "ds_read_b64_tr_b8 %12, %17 offset:4096\n\t"
+                "ds_read_b64_tr_b8 %13, %17 offset:4352\n\t"
+                "ds_read_b64_tr_b8 %14, %17 offset:6144\n\t"
+                "ds_read_b64_tr_b8 %15, %17 offset:6400\n\t"
+                "s_waitcnt lgkmcnt(0)"
+                : "=&v"(fa[0][0]), "=&v"(fa[0][1]), "=&v"(fa[1][0]), "=&v"(fa[1][1]), "=&v"(fa[2][0]), "=&v"(fa[2][1]), "=&v"(fa[3][0]),
+                  "=&v"(fa[3][1]), "=&v"(gb[0][0]), "=&v"(gb[0][1]), "=&v"(gb[1][0]), "=&v"(gb[1][1]), "=&v"(gb[2][0]), "=&v"(gb[2][1]),
+                  "=&v"(gb[3][0]), "=&v"(gb[3][1])
+                : "v"(a0), "v"(b0)
+                : "memory");
+            v4i A[4], B[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                A[i] = v4i{(int)(u32)fa[i][0], (int)(u32)(fa[i][0] >> 32), (int)(u32)fa[i][1], (int)(u32)(fa[i][1] >> 32)};
+                B[i] = v4i{(int)(u32)gb[i][0], (int)(u32)(gb[i][0] >> 32), (int)(u32)gb[i][1], (int)(u32)(gb[i][1] >> 32)};
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc[4 * i + k] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[i], B[k], acc[4 * i + k], 0, 0, 0);
+        }
+    };
+#pragma unroll
+    for (int s = 0; s < NP; ++s)
+        if (s < nsteps) issue(s, s);
+    int slot = 0; // s % NP
+    for (int t = 0; t < nt; ++t) {
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+            const int rows_done = 4 * t + rq; // output rows this wave has stored so far
+            v4i fa[4][4]; // [mt][o4]: columns 16 mt + 4 g + r of output (o4, n)
+#pragma unroll
+            for (int bp = 0; bp < 4; ++bp) {
+                const int s = 16 * t + 4 * rq + bp;
+                // Younger than R(s) when it is waited for: R(s+1) .. R(s+NP-1), four instructions each, and the two store instructions of
+                // every finished row whose stores were issued behind R(s): the row that ended e rows ago issued them behind
+                // R(s - bp - 1 - 4 (e - 1) + NP), which is R(s) or older iff bp + 1 + 4 (e - 1) <= NP.  The last NP steps of a wave drain.
+                if (s + NP <= nsteps) {
+                    constexpr int kLoads = 4 * (NP - 1);
+                    const bool st1 = bp + 1 <= NP && rows_done >= 1, st2 = bp + 5 <= NP && rows_done >= 2;
+                    if (st2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kLoads + 4) : "memory");
+                    else if (st1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kLoads + 2) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kLoads) : "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                // Operand reads as explicit instructions: a ds_read the compiler can see behind LDS-DMA into the same ring makes it
+                // insert its own s_waitcnt vmcnt(0) (it cannot see the counted waits above) -- a full drain of the stream per row.
+                v4i T[4], W[4];
+                {
+                    const u32 ta = (u32)(uintptr_t)&ring[w][slot][g >> 1][2 * n + (g & 1)]; // + 512 per output tile
+                    const u32 wa = (u32)(uintptr_t)&wl[bp][0][lane];                        // + 1024 per column tile
+                    asm volatile(
+                        "ds_read_b128 %0, %8\n\t"
+                        "ds_read_b128 %1, %8 offset:512\n\t"
+                        "ds_read_b128 %2, %8 offset:1024\n\t"
+                        "ds_read_b128 %3, %8 offset:1536\n\t"
+                        "ds_read_b128 %4, %9\n\t"
+                        "ds_read_b128 %5, %9 offset:1024\n\t"
+                        "ds_read_b128 %6, %9 offset:2048\n\t"
+                        "ds_read_b128 %7, %9 offset:3072\n\t"
+                        "s_waitcnt lgkmcnt(0)" // operands in registers before the slot is refilled
+                        : "=&v"(T[0]), "=&v"(T[1]), "=&v"(T[2]), "=&v"(T[3]), "=&v"(W[0]), "=&v"(W[1]), "=&v"(W[2]), "=&v"(W[3])
+                        : "v"(ta), "v"(wa)
+                        : "memory");
+#pragma unroll
+                    for (int o4 = 0; o4 < 4; ++o4) T[o4] ^= v4i{(int)0x80808080u, (int)0x80808080u, (int)0x80808080u, (int)0x80808080u}; // bytes as a - 128
+                }
+                if (s + NP < nsteps) issue(s + NP, slot);
+                slot = slot + 1 == NP ? 0 : slot + 1;
+                // The 16 products of the step, written out: with more than 256 registers in use the compiler gives every matrix
+                // instruction an accumulator-file destination, and that half of the file is exactly the 256 registers of the cross
+                // sums -- these 64 columns must live in the vector half, which only an explicit register class gets.  The compiler
+                // cannot see hazards inside: vector write -> matrix read is covered by the leading s_nop, matrix write -> vector read
+                // (the pack after the row's last step) by the trailing ones; accumulate chains (same destination) need none.  The
+                // row's first step starts its columns from the inline constant 0 (no 64 register initialisations per row); the
+                // columns are signed, the 2^27 that makes each non-negative is added when they are packed.
+                if (bp == 0)
+                    asm volatile("s_nop 3\n\t"
+                                 "v_mfma_i32_16x16x64_i8 %0, %16, %20, 0\n\t"
+                                 "v_mfma_i32_16x16x64_i8 %1, %16, %21, 0\n\t"
+                                 "v_mfma_i32_16x16x64_i8 %2, %16, %22, 0\n\t"
+                                 "v_mfma_i32_16x16x64_i8 %3, %16, %23, 0\n\t"
+                                 "v_mfma_i32_16x16x64_i8 %4, %17, %20, 0\n\t"
+                                 "v_mfma_i32_16x16x64_i8 %5, %17, %21, 0\n\t"
+                                 "v_mfma_i32_16x16x64_i8 %6, %17, %22, 0\n\t"
+                                 "v_mfma_i32_16x16x64_i8 %7, %17, %23, 0\n\t"
+                                 "v_mfma_i32_16x16x64_i8 %8, %18, %20, 0\n\t"
+                                 "v_mfma_i32_16x16x64_i8 %9, %18, %21, 0\n\t"
+                                 "v_mfma_i32_16x16x64_i8 %10, %18, %22, 0\n\t"
+                                 "v_mfma_i32_16x16x64_i8 %11, %18, %23, 0\n\t"
+                                 "v_mfma_i32_16x16x64_i8 %12, %19, %20, 0\n\t"
+                                 "v_mfma_i32_16x16x64_i8 %13, %19, %21, 0\n\t"
+                                 "v_mfma_i32_16x16x64_i8 %14, %19, %22, 0\n\t"
+                                 "v_mfma_i32_16x16x64_i8 %15, %19, %23, 0"
+                                 : "=&v"(fa[0][0]), "=&v"(fa[0][1]), "=&v"(fa[0][2]), "=&v"(fa[0][3]), "=&v"(fa[1][0]), "=&v"(fa[1][1]), "=&v"(fa[1][2]),
+                                   "=&v"(fa[1][3]), "=&v"(fa[2][0]), "=&v"(fa[2][1]), "=&v"(fa[2][2]), "=&v"(fa[2][3]), "=&v"(fa[3][0]), "=&v"(fa[3][1]),
+                                   "=&v"(fa[3][2]), "=&v"(fa[3][3])
+                                 : "v"(W[0]), "v"(W[1]), "v"(W[2]), "v"(W[3]), "v"(T[0]), "v"(T[1]), "v"(T[2]), "v"(T[3]));
+                else if (bp < 3)
+                    asm volatile("s_nop 3\n\t"
+                                 "v_mfma_i32_16x16x64_i8 %0, %16, %20, %0\n\t"
+                                 "v_mfma_i32_16x16x64_i8 %1, %16, %21, %1\n\t"
+                                 "v_mfma_i32_16x16x64_i8 %2, %16, %22, %2\n\t"
+                                 "v_mfma_i32_16x16x64_i8 %3, %16, %23, %3\n\t"
+                                 "v_mfma_i32_16x16x64_i8 %4, %17, %20, %4\n\t"
+                                 "v_mfma_i32_16x16x64_i8 %5, %17, %21, %5\n\t"
+                                 "v_mfma_i32_16x16x64_i8 %6, %17, %22, %6\n\t"
+                                 "v_mfma_i32_16x16x64_i8 %7, %17, %23, %7\n\t"
+                                 "v_mfma_i32_16x16x64_i8 %8, %18, %20, %8\n\t"
+                                 "v_mfma_i32_16x16x64_i8 %9, %18, %21, %9\n\t"
+                                 "v_mfma_i32_16x16x64_i8 %10, %18, %22, %10\n\t"
+                                 "v_mfma_i32_16x16x64_i8 %11, %18, %23, %11\n\t"
+                                 "v_mfma_i32_16x16x64_i8 %12, %19, %20, %12\n\t"
+                                 "v_mfma_i32_16x16x64_i8 %13, %19, %21, %13\n\t"
+                                 "v_mfma_i32_16x16x64_i8 %14, %19, %22, %14\n\t"
+                                 "v_mfma_i32_16x16x64_i8 %15, %19, %23, %15"
+                                 : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[0][2]), "+v"(fa[0][3]), "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(fa[1][2]),
+                                   "+v"(fa[1][3]), "+v"(fa[2][0]), "+v"(fa[2][1]), "+v"(fa[2][2]), "+v"(fa[2][3]), "+v"(fa[3][0]), "+v"(fa[3][1]),
+                                   "+v"(fa[3][2]), "+v"(fa[3][3])
+                                 : "v"(W[0]), "v"(W[1]), "v"(W[2]), "v"(W[3]), "v"(T[0]), "v"(T[1]), "v"(T[2]), "v"(T[3]));
+                else
+                    asm volatile("s_nop 3\n\t"
+                                 "v_mfma_i32_16x16x64_i8 %0, %16, %20, %0\n\t"
+                                 "v_mfma_i32_16x16x64_i8 %1, %16, %21, %1\n\t"
+                                 "v_mfma_i32_16x16x64_i8 %2, %16, %22, %2\n\t"
+                                 "v_mfma_i32_16x16x64_i8 %3, %16, %23, %3\n\t"
+                                 "v_mfma_i32_16x16x64_i8 %4, %17, %20, %4\n\t"
+                                 "v_mfma_i32_16x16x64_i8 %5, %17, %21, %5\n\t"
+                                 "v_mfma_i32_16x16x64_i8 %6, %17, %22, %6\n\t"
+                                 "v_mfma_i32_16x16x64_i8 %7, %17, %23, %7\n\t"
+                                 "v_mfma_i32_16x16x64_i8 %8, %18, %20, %8\n\t"
+                                 "v_mfma_i32_16x16x64_i8 %9, %18, %21, %9\n\t"
+                                 "v_mfma_i32_16x16x64_i8 %10, %18, %22, %10\n\t"
+                                 "v_mfma_i32_16x16x64_i8 %11, %18, %23, %11\n\t"
+                                 "v_mfma_i32_16x16x64_i8 %12, %19, %20, %12\n\t"
+                                 "v_mfma_i32_16x16x64_i8 %13, %19, %21, %13\n\t"
+                                 "v_mfma_i32_16x16x64_i8 %14, %19, %22, %14\n\t"
+                                 "v_mfma_i32_16x16x64_i8 %15, %19, %23, %15\n\t"
+                                 "s_nop 15\n\t"
+                                 "s_nop 7"
+                                 : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[0][2]), "+v"(fa[0][3]), "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(fa[1][2]),
+                                   "+v"(fa[1][3]), "+v"(fa[2][0]), "+v"(fa[2][1]), "+v"(fa[2][2]), "+v"(fa[2][3]), "+v"(fa[3][0]), "+v"(fa[3][1]),
+                                   "+v"(fa[3][2]), "+v"(fa[3][3])
+                                 : "v"(W[0]), "v"(W[1]), "v"(W[2]), "v"(W[3]), "v"(T[0]), "v"(T[1]), "v"(T[2]), "v"(T[3]));
+            }
+            const fq o = mfma_fold_finish(fa, kfix, c1, c8, c16, c24);
+            fq* out = dst + (e0 + (size_t)rq) * qn + base0 + (size_t)t * stride + lane;
+            if (BIG) fq_store_stream(out, o); else fq_store(out, o);
+            if (rq == 0 && t > 0) { // every wave has finished the matrix stage of tile t - 1: the tile buffer is free
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+            }
+            tile[4 * w + rq][2 * lane] = u32x4{o.v[0] ^ 0x80808080u, o.v[1] ^ 0x80808080u, o.v[2] ^ 0x80808080u, o.v[3] ^ 0x80808080u};
+            tile[4 * w + rq][2 * lane + 1] = u32x4{o.v[4] ^ 0x80808080u, o.v[5] ^ 0x80808080u, o.v[6] ^ 0x80808080u, o.v[7] ^ 0x80808080u};
+            u32 c = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) pls[w][rq][k][lane] = __builtin_addc(pls[w][rq][k][lane], o.v[k], c, &c);
+            pls[w][rq][8][lane] += c;
+            __builtin_amdgcn_sched_barrier(0); // rows are unrolled for the static pl index only: no scheduling across rows (register pressure)
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // this wave's four tile rows are written
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        matrix_stage();
+    }
+    // ---- epilogue: once per wave (as k_cross64_mfma)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads(); // every wave is done with the tile: it becomes scratch (4 KiB per wave)
+    int* mat = reinterpret_cast<int*>(&tile[0][0]) + w * 1024;
+    const fq r2 = {FQ_R2_LIMBS};
+    fq* out = partials + ((size_t)term * gridDim.x + blockIdx.x) * (NE * NE + 2 * NE);
+    fq wk;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) wk.v[k] = kPow256ModP[lane < 63 ? lane : 0][k];
+    for (int e = 0; e < 16; ++e) { // rolled: the body is large and runs once
+        v16i a = acc[0];
+#pragma unroll
+        for (int e2 = 1; e2 < 16; ++e2)
+            if (e == e2) a = acc[e2];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) mat[((k & 3) + 8 * (k >> 2) + 4 * (lane >> 5)) * 32 + (lane & 31)] = a[k];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        long long d = 0;
+        const int klo = lane > 31 ? lane - 31 : 0, khi = lane < 31 ? lane : 31;
+        for (int i = klo; i <= khi && lane < 63; ++i) d += mat[i * 32 + (lane - i)];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const bool neg = d < 0;
+        const unsigned long long ad = (unsigned long long)(neg ? -d : d);
+        fq xx = fq_zero();
+        xx.v[0] = (u32)ad;
+        xx.v[1] = (u32)(ad >> 32);
+        fq prod = fq_mul(xx, wk);
+        if (neg) prod = fq_sub(fq_zero(), prod);
+        const fq mine = fq_wave_sum(prod);
+        if (lane == 0) fq_store(out + NE * (4 * fi + (e >> 2)) + 4 * gi + (e & 3), mine);
+    }
+    for (int row = 0; row < 4; ++row) { // rolled; tile rows 4w + row: rows 0..7 = A_e, rows 8..15 = B_e'
+        fq lo, hi = fq_zero();
+#pragma unroll
+        for (int k = 0; k < 8; ++k) lo.v[k] = pls[w][row][k][lane];
+        hi.v[0] = pls[w][row][8][lane];
+        const fq sum = fq_wave_sum(fq_add(fq_reduce_256(lo), fq_mul(hi, r2)));
+        if (lane == 0) fq_store(out + NE * NE + 4 * w + row, sum);
+    }
+}
+
 // second stage: one block per (term, value): red[term * nv + v] = sum over the workgroups (fixed order)
 __global__ void __launch_bounds__(kThreads) k_reduce_cross(const fq* __restrict__ partials, int gx, int nv, fq* __restrict__ red) {
     const int term = blockIdx.x / nv, v = blockIdx.x % nv;
@@ -1018,7 +1378,6 @@ void launch_fold3_cross64(const void* const s[4], void* const d[4], size_t outle
     Tab4 S;
     Tab4w D;
     for (int k = 0; k < 4; ++k) { S.t[k] = (const fq*)s[k]; D.t[k] = (fq*)d[k]; }
-    launch_eq_weights28(r3, 3, two24, wbuf, st);
     const size_t q = outlen / 8;
     size_t gx = std::min<size_t>(q / 64, 128);
     const size_t need = (q + ((size_t)1 << 16) - 1) >> 16;
@@ -1028,6 +1387,20 @@ void launch_fold3_cross64(const void* const s[4], void* const d[4], size_t outle
     qn.v[0] = (u32)q;
     qn.v[1] = (u32)((u64)q >> 32);
     const bool stream_stores = gates.wide_stream_from_log < 63 && outlen >= ((size_t)1 << std::max(gates.wide_stream_from_log, 0));
+    if (ring == 8 || (ring >= 12 && ring <= 14)) { // the fold on the matrix cores too (k_fold3_cross64_mfma); 12..14: ring of 2..4 steps (8 = 4)
+        launch_eq_weights_mfma(r3, 3, two24, wbuf, st);
+        const fq kfix = ZK_MFMA_FOLD_FIX;
+        g_forms |= kFormFold3Cross64Mfma;
+        const int np = ring == 8 ? 4 : ring - 10;
+#define ZK_F3M(BV, NV) hipLaunchKernelGGL((k_fold3_cross64_mfma<BV, NV>), dim3((unsigned)gx, 2), dim3(256), 0, st, S, D, outlen, (const u32x4*)wbuf, kfix, (fq*)partials)
+        if (stream_stores) { if (np == 2) ZK_F3M(true, 2); else if (np == 3) ZK_F3M(true, 3); else ZK_F3M(true, 4); }
+        else { if (np == 2) ZK_F3M(false, 2); else if (np == 3) ZK_F3M(false, 3); else ZK_F3M(false, 4); }
+#undef ZK_F3M
+        hipLaunchKernelGGL(k_reduce_cross, dim3(160), dim3(kThreads), 0, st, (const fq*)partials, (int)gx, 80, red);
+        hipLaunchKernelGGL(k_cross64_fix, dim3(1), dim3(128), 0, st, (const fq*)red, qn, (fq*)out);
+        return;
+    }
+    launch_eq_weights28(r3, 3, two24, wbuf, st);
     g_forms |= kFormFold3Cross64;
 #define ZK_F3X(BV, DV) hipLaunchKernelGGL((k_fold3_cross64<BV, DV>), dim3((unsigned)gx, 2), dim3(512), 0, st, S, D, outlen, (const u32*)wbuf, (fq*)partials)
     if (stream_stores) { if (ring == 5) ZK_F3X(true, 5); else if (ring == 3) ZK_F3X(true, 3); else ZK_F3X(true, 4); }

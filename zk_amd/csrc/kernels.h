@@ -37,6 +37,7 @@ enum Form : unsigned {
     kFormCross64 = 1u << 14,      // k_cross64_mfma (three rounds per pass: 8 x 8 cross sums per term on the matrix cores)
     kFormFold3Dma = 1u << 15,     // m = 3 LDS-DMA fold of the degree-2 branch (three rounds per pass)
     kFormFold3Cross64 = 1u << 16, // k_fold3_cross64 (that fold fused with the next level's cross sums)
+    kFormFold3Cross64Mfma = 1u << 17, // k_fold3_cross64_mfma (the same sweep with the fold on the matrix cores)
 };
 extern thread_local unsigned g_forms;
 // Size thresholds of the LDS-DMA forms (log2 of entries; defaults = the measured break-even points)
@@ -50,7 +51,8 @@ struct DmaGates {
     int wide_mfma_depth = 2;       // its pipeline depth K (2..4): table rows of K steps in flight per wave
     int deg2_triple_from_log = 21; // degree-2 prover: three rounds per pass (k_cross64_mfma + m = 3 fold) on tables of >= 2^k entries; 64 = never
     int deg2_fused_below_log = 20; // degree-2 prover: fold + nine sums in one kernel (k_fold2_sum9) for folded tables below 2^k entries; 0 = never
-    int deg2_fold3_fused = 4;      // three-round passes: fold fused with the next level's cross sums (k_fold3_cross64); value = DMA slots per wave (3..5), 0 = off
+    int deg2_fold3_fused = 8;      // three-round passes: fold fused with the next level's cross sums; 8 = the fold on the matrix cores too
+                                   // (k_fold3_cross64_mfma, ring of 4 steps; 12..14: 2..4 steps), 3..5 = DMA slots per wave of the VALU-fold form (k_fold3_cross64), 0 = off
     int deg2_triple_ring = 4;      // its LDS ring: 3 or 4 tiles of 32 KiB
 };
 // out[b] (b < 2^log_ob) = sum of the b-th contiguous block of T (L entries); partials is scratch

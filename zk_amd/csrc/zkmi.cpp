@@ -1301,7 +1301,7 @@ int zk_ctx_set_deg2_triple(zk_ctx* c, int from_log, int ring) {
     return ZK_OK;
 }
 int zk_ctx_set_deg2_fold3_fused(zk_ctx* c, int dma_slots) {
-    if (!c || (dma_slots != 0 && (dma_slots < 3 || dma_slots > 5))) return ZK_E_ARG;
+    if (!c || (dma_slots != 0 && dma_slots != 8 && (dma_slots < 3 || dma_slots > 5) && (dma_slots < 12 || dma_slots > 14))) return ZK_E_ARG;
     c->gates.deg2_fold3_fused = dma_slots;
     return ZK_OK;
 }
