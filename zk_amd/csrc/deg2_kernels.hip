@@ -1310,8 +1310,8 @@ void launch_fold4(const void* const s[4], void* const d[4], size_t half, const u
     for (int k = 0; k < 4; ++k) { S.t[k] = (const fq*)s[k]; D.t[k] = (fq*)d[k]; }
     hipLaunchKernelGGL(k_fold4, dim3(grid_for(half)), dim3(kThreads), 0, st, S, D, half, to_fq(r));
 }
-void launch_sum9(const void* const t[4], size_t q, const uint64_t fix24[4], int lazy_from_log, void* partials, void* out, hipStream_t st,
-                 const DmaGates& gates) {
+int launch_sum9(const void* const t[4], size_t q, const uint64_t fix24[4], int lazy_from_log, void* partials, void* out, hipStream_t st,
+                const DmaGates& gates, bool allow_u) {
     Tab4 T;
     for (int k = 0; k < 4; ++k) T.t[k] = (const fq*)t[k];
     if (gates.sum9_mfma_from_log < 63 && q % 64 == 0 && q >= ((size_t)1 << std::max(gates.sum9_mfma_from_log, 0)) &&
@@ -1328,7 +1328,7 @@ void launch_sum9(const void* const t[4], size_t q, const uint64_t fix24[4], int 
         hipLaunchKernelGGL(k_sum16_mfma, dim3((unsigned)gx, 2), dim3(kThreads), 0, st, T, q, (fq*)partials);
         hipLaunchKernelGGL(k_reduce48, dim3(48), dim3(kThreads), 0, st, (const fq*)partials, (int)gx, red);
         hipLaunchKernelGGL(k_sum9_from_p16, dim3(1), dim3(64), 0, st, (const fq*)red, qn, (fq*)out);
-        return;
+        return 0;
     }
     if (lazy_from_log >= 0 && lazy_from_log < 63 && q >= 64 && q >= ((size_t)1 << lazy_from_log)) { // large: unreduced accumulation, one wave per Y
         size_t gx = (q + 63) / 64;
@@ -1338,9 +1338,13 @@ void launch_sum9(const void* const t[4], size_t q, const uint64_t fix24[4], int 
         fq* u = (fq*)partials + (size_t)18 * gx; // nine U sums, behind the partials
         g_forms |= kFormSum9Lazy;
         hipLaunchKernelGGL(k_sum9_lazy, dim3((unsigned)gx, 2), dim3(64, 9), 0, st, T, q, to_fq(fix24), (fq*)partials);
+        if (allow_u) { // the caller maps U to the nine sums on the host (a few additions): one launch less on the critical path
+            hipLaunchKernelGGL(k_reduce9, dim3(9), dim3(kThreads), 0, st, (const fq*)partials, (int)gx, 1, (fq*)out);
+            return 1;
+        }
         hipLaunchKernelGGL(k_reduce9, dim3(9), dim3(kThreads), 0, st, (const fq*)partials, (int)gx, 1, u);
         hipLaunchKernelGGL(k_sum9_from_u, dim3(1), dim3(64), 0, st, (const fq*)u, (fq*)out);
-        return;
+        return 0;
     }
     size_t gx = (q + kThreads - 1) / kThreads;
     if (gx < 1) gx = 1;
@@ -1350,6 +1354,7 @@ void launch_sum9(const void* const t[4], size_t q, const uint64_t fix24[4], int 
     if (ysplit) hipLaunchKernelGGL((k_sum9<true>), dim3((unsigned)gx, 6), dim3(kThreads), 0, st, T, q, (fq*)partials);
     else hipLaunchKernelGGL((k_sum9<false>), dim3((unsigned)gx, 2), dim3(kThreads), 0, st, T, q, (fq*)partials);
     hipLaunchKernelGGL(k_reduce9, dim3(9), dim3(kThreads), 0, st, (const fq*)partials, (int)gx, ysplit ? 1 : 0, (fq*)out);
+    return 0;
 }
 // a workgroup's i32 accumulators take 2^16 quarter-indices: |byte - 128| <= 128, so a product is <= 2^14 and 2^16 of them stay below
 // 2^31 with a factor of two to spare (2^17 all-zero entries would reach exactly 2^31)
@@ -1367,7 +1372,8 @@ void launch_cross64(const void* const t[4], size_t q, int ring, void* partials, 
     qn.v[0] = (u32)q;
     qn.v[1] = (u32)((u64)q >> 32);
     g_forms |= kFormCross64;
-    if (ring == 4) hipLaunchKernelGGL((k_cross64_mfma<4>), dim3((unsigned)gx, 2), dim3(512), 0, st, T, q, (fq*)partials);
+    if (ring == 5) hipLaunchKernelGGL((k_cross64_mfma<5>), dim3((unsigned)gx, 2), dim3(512), 0, st, T, q, (fq*)partials);
+    else if (ring == 4) hipLaunchKernelGGL((k_cross64_mfma<4>), dim3((unsigned)gx, 2), dim3(512), 0, st, T, q, (fq*)partials);
     else hipLaunchKernelGGL((k_cross64_mfma<3>), dim3((unsigned)gx, 2), dim3(512), 0, st, T, q, (fq*)partials);
     hipLaunchKernelGGL(k_reduce_cross, dim3(160), dim3(kThreads), 0, st, (const fq*)partials, (int)gx, 80, red);
     hipLaunchKernelGGL(k_cross64_fix, dim3(1), dim3(128), 0, st, (const fq*)red, qn, (fq*)out);
@@ -1470,7 +1476,8 @@ void launch_fold2_tables(const void* const s[4], void* const d[4], size_t outlen
     hipLaunchKernelGGL(k_fold2_tables, dim3((unsigned)gx, 4), dim3(kThreads), 0, st, S, D, outlen, W);
 }
 // the fold of launch_fold2_tables and the nine sums of its result (launch_sum9 on d[]) in one launch + the second stage: small tables
-void launch_fold2_sum9(const void* const s[4], void* const d[4], size_t outlen, const uint32_t* w28, void* partials, void* out, hipStream_t st) {
+int launch_fold2_sum9(const void* const s[4], void* const d[4], size_t outlen, const uint32_t* w28, void* partials, void* out, hipStream_t st,
+                      int host_groups_max) {
     Tab4 S;
     Tab4w D;
     for (int k = 0; k < 4; ++k) { S.t[k] = (const fq*)s[k]; D.t[k] = (fq*)d[k]; }
@@ -1481,8 +1488,13 @@ void launch_fold2_sum9(const void* const s[4], void* const d[4], size_t outlen, 
     if (gx < 1) gx = 1;
     if (gx > (size_t)kMaxBlocks9) gx = kMaxBlocks9; // 512 and 256 measure the same on GKR config 5
     g_forms |= kFormFold2Sum9;
+    if (2 * gx <= (size_t)host_groups_max) { // few workgroups: their partial sums go straight to `out` and the caller adds them -- no second stage
+        hipLaunchKernelGGL(k_fold2_sum9, dim3((unsigned)gx, 2), dim3(kThreads), 0, st, S, D, outlen, W, (fq*)out);
+        return (int)(2 * gx);
+    }
     hipLaunchKernelGGL(k_fold2_sum9, dim3((unsigned)gx, 2), dim3(kThreads), 0, st, S, D, outlen, W, (fq*)partials);
     hipLaunchKernelGGL(k_reduce9, dim3(9), dim3(kThreads), 0, st, (const fq*)partials, (int)gx, 0, (fq*)out);
+    return 0;
 }
 
 } // namespace zkk

@@ -58,6 +58,10 @@ struct zk_circuit {
     zk_ctx* ctx;
     int device;
     std::vector<LayerDev> layers; // layers[0] is next to the inputs (circuit.rs:11)
+    // the prover's layer evaluations (circuit_evaluations, gkr/src/prover.rs:30), kept between proofs (grow-only): 17 hipMalloc + 17
+    // hipFree of 32 MiB per prove at BASELINE config 5 were 3 ms of host time
+    void* ev_buf = nullptr;
+    size_t ev_cap = 0; // bytes
 };
 
 namespace {
@@ -97,7 +101,7 @@ int zk_circuit_create(zk_ctx* c, const uint64_t* gates, const size_t* layer_len,
     if (!c || !out || (n_layers && (!gates || !layer_len))) return ZK_E_ARG;
     int rc = set_device(c);
     if (rc) return rc;
-    zk_circuit* ci = new (std::nothrow) zk_circuit{c, c->device, {}};
+    zk_circuit* ci = new (std::nothrow) zk_circuit{c, c->device, {}, nullptr, 0};
     if (!ci) return ZK_E_ALLOC;
     ci->layers.resize(n_layers);
     size_t off = 0;
@@ -142,6 +146,7 @@ void zk_circuit_free(zk_circuit* ci) {
     for (auto& L : ci->layers)
         for (void* p : {(void*)L.left, (void*)L.right, (void*)L.op, (void*)L.lptr, (void*)L.lidx, (void*)L.rptr, (void*)L.ridx})
             if (p) (void)hipFree(p);
+    if (ci->ev_buf) (void)hipFree(ci->ev_buf);
     delete ci;
 }
 
@@ -276,18 +281,38 @@ static int gkr_prove_impl(zk_ctx* c, zk_circuit* ci, zk_transcript* tr, const zk
     int rc = set_device(c);
     if (rc) return rc;
 
-    std::vector<zk_mle*> ev(L + 1, nullptr); // circuit_evaluations, :30
-    struct Free { std::vector<zk_mle*>& v; ~Free() { for (auto* m : v) zk_mle_free(m); } } free_ev{ev};
+    // circuit_evaluations (:30): ev[0] = the inputs (read in place), ev[i + 1] = outputs of layers[i], in the circuit's own buffer
+    struct Tab { const void* d; size_t len; };
+    std::vector<Tab> ev(L + 1);
     const auto t_start = std::chrono::steady_clock::now();
-    if ((rc = zk_circuit_evaluate(ci, inputs, ev.data()))) return rc;
+    {
+        size_t total = 0;
+        for (size_t i = 0; i < L; ++i) total += ci->layers[i].n_out;
+        if (ci->ev_cap < total * kElem) {
+            if (ci->ev_buf) { HIPCHK(c, hipFree(ci->ev_buf)); ci->ev_buf = nullptr; ci->ev_cap = 0; }
+            HIPCHK(c, hipMalloc(&ci->ev_buf, total * kElem));
+            ci->ev_cap = total * kElem;
+        }
+        ev[0] = Tab{inputs->d, inputs->len};
+        uint8_t* at = (uint8_t*)ci->ev_buf;
+        for (size_t i = 0; i < L; ++i) { // evaluate_at_input, circuit.rs:37-59
+            const LayerDev& Ly = ci->layers[i];
+            if (Ly.max_index >= ev[i].len) return ZK_E_ARG; // running_inputs[gate.left] out of bounds panics, circuit.rs:47-48
+            zkk::launch_circuit_layer(ev[i].d, at, Ly.left, Ly.right, Ly.op, Ly.n_gates, Ly.n_out, c->stream);
+            ev[i + 1] = Tab{at, Ly.n_out};
+            at += Ly.n_out * kElem;
+        }
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
     const auto t_eval = std::chrono::steady_clock::now();
 
     // every layer's relation needs 2^k_in == len(W_{i+1}) (ProductPolynomial::new panics otherwise, product_polynomial.rs:15-19)
     size_t max_in = 2, max_out = 2;
     for (size_t i = 0; i < L; ++i) {
         const LayerDev& Ly = ci->layers[i];
-        if (((size_t)1 << Ly.k_in) != ev[i]->len || Ly.k_in < 1) return ZK_E_LEN_MISMATCH;
-        max_in = std::max(max_in, ev[i]->len);
+        if (((size_t)1 << Ly.k_in) != ev[i].len || Ly.k_in < 1) return ZK_E_LEN_MISMATCH;
+        max_in = std::max(max_in, ev[i].len);
         max_out = std::max(max_out, Ly.n_out);
     }
     const size_t half_tab = (size_t)1 << zkk::kMaxEqVars;
@@ -308,7 +333,8 @@ static int gkr_prove_impl(zk_ctx* c, zk_circuit* ci, zk_transcript* tr, const zk
     void* eqs[4] = {take(eq_half), take(eq_half), take(eq_half), take(eq_half)};
     zkk::launch_fill_one(ones, max_in, c->stream);
 
-    const zk_mle* W0 = ev[L]; // get_w_i(0), :43
+    const zk_mle w0_view{c, const_cast<void*>(ev[L].d), ev[L].len, false, c->device}; // get_w_i(0), :43 (not owned)
+    const zk_mle* W0 = &w0_view;
     const unsigned k0 = ilog2(W0->len);
     // proof.output_poly: the copy into the caller's (pageable) buffer runs on a helper thread and its own stream while
     // this thread feeds the output layer through the Keccak sponge (:46) -- both read W0, neither writes it
@@ -353,7 +379,7 @@ static int gkr_prove_impl(zk_ctx* c, zk_circuit* ci, zk_transcript* tr, const zk
     hipEvent_t& ev_b = evs.b;
     for (size_t layer_idx = 0; layer_idx < L; ++layer_idx) {
         const LayerDev& Ly = ci->layers[L - 1 - layer_idx];
-        const zk_mle* Wn = ev[L - 1 - layer_idx]; // next_w_i, :125
+        const Tab* Wn = &ev[L - 1 - layer_idx]; // next_w_i, :125
         const int k_in = Ly.k_in, k_out = Ly.k_out;
         const size_t n_in = (size_t)1 << k_in;
         if (layer_ms_out) HIPCHK(c, hipEventRecord(ev_a, c->stream));

@@ -88,8 +88,10 @@ static constexpr int kMaxBlocks9 = 1024;
 static constexpr size_t kSum9PartialElems = (size_t)160 * kMaxBlocks9 + 256; // elements `partials` must hold for launch_sum9 / launch_cross64
 // fix24 = 2^24 (Montgomery); tables of at least 2^lazy_from_log quarter-entries take the unreduced-accumulation kernel
 // (lazy_from_log < 0: never)
-void launch_sum9(const void* const t[4], size_t q, const uint64_t fix24[4], int lazy_from_log, void* partials, void* out, hipStream_t st,
-                 const DmaGates& gates = DmaGates());
+// Returns 0 when out holds the nine sums; with allow_u, 1 when it holds the nine U sums of k_sum9_lazy instead (out[3 b + a]; the
+// caller applies k_sum9_from_u's linear maps on the host: one launch less on the critical path of a latency-bound pass)
+int launch_sum9(const void* const t[4], size_t q, const uint64_t fix24[4], int lazy_from_log, void* partials, void* out, hipStream_t st,
+                const DmaGates& gates = DmaGates(), bool allow_u = false);
 // bind the two top variables of four tables of 4*outlen entries (w28: the 4 eq weights as for launch_multifold_lazy)
 // into d[] (outlen entries each)
 // wbuf (device, >= 40 u32) and partials (>= 1024 elements) are scratch for the large-table form; either may be null (then never used)
@@ -104,7 +106,11 @@ void launch_cross64(const void* const t[4], size_t q, int ring, void* partials, 
 void launch_fold3_tables(const void* const s[4], void* const d[4], size_t outlen, const uint64_t* r3, const uint64_t two24[4], void* wbuf,
                          void* partials, hipStream_t st, const DmaGates& gates = DmaGates());
 // launch_fold2_tables followed by launch_sum9 on its result, as one kernel + the second stage (small, cache-resident tables; outlen >= 4)
-void launch_fold2_sum9(const void* const s[4], void* const d[4], size_t outlen, const uint32_t* w28, void* partials, void* out, hipStream_t st);
+// Returns 0 when out holds the nine sums.  With at most host_groups_max workgroups in the launch (out must then hold 9 elements per
+// workgroup, normally pinned host memory) there is no second stage: returns G = the number of workgroups, out[g * 9 + s] = workgroup
+// g's share of sum s, and the caller adds the G shares.
+int launch_fold2_sum9(const void* const s[4], void* const d[4], size_t outlen, const uint32_t* w28, void* partials, void* out, hipStream_t st,
+                      int host_groups_max = 0);
 // launch_fold3_tables followed by launch_cross64 on d[], in one sweep: the folded tables are not re-read (needs cross64_fits(outlen / 8));
 // ring = LDS-DMA slots per wave (3, 4 or 5)
 void launch_fold3_cross64(const void* const s[4], void* const d[4], size_t outlen, const uint64_t* r3, const uint64_t two24[4], void* wbuf,

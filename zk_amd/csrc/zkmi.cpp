@@ -78,6 +78,9 @@ void zk_ctx_destroy(zk_ctx* c) {
     if (c->sums_dev) (void)hipFree(c->sums_dev);
     if (c->wide_w) (void)hipFree(c->wide_w);
     if (c->sums_host) (void)hipHostFree(c->sums_host);
+    if (c->le_host) (void)hipHostFree(c->le_host);
+    for (hipEvent_t e : c->le_ev)
+        if (e) (void)hipEventDestroy(e);
     if (c->work[0]) (void)hipFree(c->work[0]);
     if (c->work[1]) (void)hipFree(c->work[1]);
     if (c->stage) (void)hipFree(c->stage);
@@ -901,14 +904,44 @@ static int prove_sum2x2_pairs(zk_ctx* c, const void* const tables[4], size_t len
     unsigned k = 0; // round index
     int pass = 0;
     // the sums sweep over four tables of n entries; returns the rounds it serves (3: cross sums, 2: nine sums)
+    // what the pinned buffer holds after a two-round sums launch: the nine sums (0 groups), G workgroups' shares of them (G > 0), or the
+    // nine U sums of k_sum9_lazy (kU) -- the last two are finished here on the host instead of by one more small launch
+    constexpr int kU = -1;
+    int sums_kind = 0;
     auto launch_sums = [&](const void* const t[4], size_t n) -> int {
         ProfScope ps(c, ZK_K_SUM9, (uint64_t)n * 32 * 4);
         if (deg2_triple_ok(c, n)) {
             zkk::launch_cross64(t, n / 8, c->gates.deg2_triple_ring, c->partials, c->sums_host_dev, c->stream); // 128 cross sums straight into pinned host memory
             return 3;
         }
-        zkk::launch_sum9(t, n / 4, c->two24, c->deg2_lazy_from_log, c->partials, c->sums_host_dev, c->stream, c->gates); // nine sums, likewise
+        sums_kind = zkk::launch_sum9(t, n / 4, c->two24, c->deg2_lazy_from_log, c->partials, c->sums_host_dev, c->stream, c->gates, true) ? kU : 0;
         return 2;
+    };
+    auto nine_sums = [&](Fq S[9]) {
+        if (sums_kind > 0) { // shares of sums_kind workgroups, fixed order
+            for (int i = 0; i < 9; ++i) {
+                Fq a = zkh::zero();
+                for (int g = 0; g < sums_kind; ++g) a = zkh::add(a, zkh::load(c->sums_host + 4 * ((size_t)g * 9 + i)));
+                S[i] = a;
+            }
+        } else if (sums_kind == kU) { // k_sum9_from_u's maps: V[a][Y] = U[a][Y] (Y < 2), V[a][2] = 3 U[a][0] + 6 U[a][1] - 2 U[a][+]
+            Fq U[9];
+            for (int i = 0; i < 9; ++i) U[i] = zkh::load(c->sums_host + 4 * i);
+            for (int Y = 0; Y < 3; ++Y) {
+                Fq V[3];
+                for (int a = 0; a < 3; ++a) {
+                    if (Y < 2) { V[a] = U[3 * Y + a]; continue; }
+                    const Fq u0 = U[a], u1 = U[3 + a], up = U[6 + a], u1x2 = zkh::add(u1, u1);
+                    V[a] = zkh::sub(zkh::add(zkh::add(zkh::add(u0, u0), u0), zkh::add(zkh::add(u1x2, u1x2), u1x2)), zkh::add(up, up));
+                }
+                S[3 * Y] = V[0];
+                S[3 * Y + 1] = V[1];
+                const Fq v01 = zkh::add(V[0], V[1]);
+                S[3 * Y + 2] = zkh::sub(zkh::add(v01, v01), V[2]);
+            }
+        } else {
+            for (int i = 0; i < 9; ++i) S[i] = zkh::load(c->sums_host + 4 * i);
+        }
     };
     int K = 0;
     if (curlen > kHostTail) K = launch_sums(cur, curlen);
@@ -922,7 +955,7 @@ static int prove_sum2x2_pairs(zk_ctx* c, const void* const tables[4], size_t len
             host_rounds_from_cross(tr, 3, P, coeffs_out + 12 * k, rs);
         } else {
             Fq S[9];
-            for (int i = 0; i < 9; ++i) S[i] = zkh::load(c->sums_host + 4 * i);
+            nine_sums(S);
             host_round_pair_from_sum9(tr, S, coeffs_out + 12 * k, rs);
         }
         if (challenges_out) std::memcpy(challenges_out + 4 * k, rs, (size_t)K * kElem);
@@ -943,7 +976,7 @@ static int prove_sum2x2_pairs(zk_ctx* c, const void* const tables[4], size_t len
             ProfScope ps(c, ZK_K_FOLD2X4_SUM9, (uint64_t)curlen * 32 * 4 + (uint64_t)outlen * 32 * 4);
             uint32_t w28[4 * 10];
             eq_weights28(rs, 2, w28);
-            zkk::launch_fold2_sum9(cur, dst, outlen, w28, c->partials, c->sums_host_dev, c->stream);
+            sums_kind = zkk::launch_fold2_sum9(cur, dst, outlen, w28, c->partials, c->sums_host_dev, c->stream, kHostSumGroups);
         } else {
             {
                 ProfScope ps(c, ZK_K_FOLD2X4_SUM9, (uint64_t)curlen * 32 * 4 + (uint64_t)outlen * 32 * 4);
@@ -1295,7 +1328,7 @@ int zk_ctx_set_deg2_fused(zk_ctx* c, int below_log) {
     return ZK_OK;
 }
 int zk_ctx_set_deg2_triple(zk_ctx* c, int from_log, int ring) {
-    if (!c || from_log < 0 || from_log > 64 || (ring != 3 && ring != 4)) return ZK_E_ARG;
+    if (!c || from_log < 0 || from_log > 64 || (ring < 3 || ring > 5)) return ZK_E_ARG;
     c->gates.deg2_triple_from_log = from_log;
     c->gates.deg2_triple_ring = ring;
     return ZK_OK;

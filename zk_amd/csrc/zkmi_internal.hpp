@@ -22,9 +22,12 @@ using zkh::Fq;
 namespace zki {
 constexpr size_t kElem = 32;
 constexpr size_t kChunkElems = (size_t)1 << 21; // 64 MiB staging chunks for byte conversion
+constexpr size_t kLeChunkElems = (size_t)1 << 19; // to_bytes: 16 MiB halves of the pinned staging buffer
 constexpr size_t kSums = (size_t)1 << zkk::kMaxFoldBatch; // block sums per pass
 constexpr size_t kHostTail = 64;                // degree-2 prover: tables of <= this many entries are finished on the host
-constexpr size_t kHostStage = 4 * kHostTail;    // elements of the pinned staging buffer
+constexpr int kHostSumGroups = 32;              // fold + nine-sum passes of <= this many workgroups leave their partial sums to the host
+constexpr size_t kHostStage = 9 * kHostSumGroups; // elements of the pinned staging buffer (>= 4 * kHostTail)
+static_assert(kHostStage >= 4 * kHostTail, "the staging buffer receives the four tail tables");
 static_assert(kHostStage >= kSums, "the staging buffer also receives the block sums of a pass");
 
 inline bool is_pow2(size_t n) { return n && !(n & (n - 1)); }
@@ -82,6 +85,9 @@ struct zk_ctx {
     void* work[2] = {nullptr, nullptr};
     size_t work_cap[2] = {0, 0}; // bytes
     void* stage = nullptr;       // kChunkElems elements
+    uint8_t* le_host = nullptr;  // to_bytes staging: pinned + device-mapped, 2 x kLeChunkElems elements (stream_le32), made on first use
+    void* le_host_dev = nullptr; // its device address
+    hipEvent_t le_ev[2] = {nullptr, nullptr};
     void* gkr_scratch = nullptr; // layer prover's tables (gkr.cpp), kept between proofs: grow-only
     size_t gkr_scratch_cap = 0;  // bytes
     std::string err;
@@ -264,19 +270,32 @@ inline int new_mle(zk_ctx* c, size_t len, zk_mle** out) {
     return ZK_OK;
 }
 
-// to_bytes of a table fed to `sink` in chunks (device converts, host receives LE32 bytes)
+// to_bytes of a table fed to `sink` in chunks.  The conversion kernel stores the LE32 bytes straight into device-mapped pinned host
+// memory (no copy command: a 32 MiB device-to-host copy into pageable memory was 64 staged blit kernels), in two halves so that chunk
+// i + 1 is converted while the host consumes chunk i (the sink is a Keccak absorb at ~0.6 GB/s: the device side hides under it).
 template <class Sink>
 int stream_le32(zk_ctx* c, const void* table, size_t len, Sink&& sink) {
-    int rc = ensure_stage(c);
-    if (rc) return rc;
-    std::vector<uint8_t> host(std::min(len, kChunkElems) * kElem);
-    for (size_t off = 0; off < len; off += kChunkElems) {
-        size_t n = std::min(kChunkElems, len - off);
-        zkk::launch_to_le32((const uint8_t*)table + off * kElem, c->stage, n, c->stream);
+    if (!c->le_host) {
+        HIPCHK(c, hipHostMalloc((void**)&c->le_host, 2 * kLeChunkElems * kElem, hipHostMallocMapped));
+        HIPCHK(c, hipHostGetDevicePointer(&c->le_host_dev, c->le_host, 0));
+        HIPCHK(c, hipEventCreateWithFlags(&c->le_ev[0], hipEventDisableTiming));
+        HIPCHK(c, hipEventCreateWithFlags(&c->le_ev[1], hipEventDisableTiming));
+    }
+    const size_t nchunks = (len + kLeChunkElems - 1) / kLeChunkElems;
+    auto convert = [&](size_t i) -> int {
+        const size_t off = i * kLeChunkElems, n = std::min(kLeChunkElems, len - off);
+        zkk::launch_to_le32((const uint8_t*)table + off * kElem, (uint8_t*)c->le_host_dev + (i & 1) * kLeChunkElems * kElem, n, c->stream);
         HIPCHK(c, hipGetLastError());
-        HIPCHK(c, hipMemcpyAsync(host.data(), c->stage, n * kElem, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        sink(host.data(), n * kElem, off);
+        HIPCHK(c, hipEventRecord(c->le_ev[i & 1], c->stream));
+        return ZK_OK;
+    };
+    int rc;
+    if (nchunks && (rc = convert(0))) return rc;
+    for (size_t i = 0; i < nchunks; ++i) {
+        if (i + 1 < nchunks && (rc = convert(i + 1))) return rc; // its half was consumed by the sink one iteration ago
+        HIPCHK(c, hipEventSynchronize(c->le_ev[i & 1]));
+        const size_t off = i * kLeChunkElems, n = std::min(kLeChunkElems, len - off);
+        sink(c->le_host + (i & 1) * kLeChunkElems * kElem, n * kElem, off);
     }
     return ZK_OK;
 }
