@@ -744,6 +744,14 @@ void launch_eq_weights_mfma(const uint64_t* r, int m, const uint64_t two24[4], v
     ch.two24 = to_fq(two24);
     hipLaunchKernelGGL(k_eq_weights_mfma, dim3(1u << (m - 1)), dim3(kThreads), 0, st, ch, m, (u32*)wbuf);
 }
+// A pass cut into 2^log_ob output blocks leaves one partial sum per workgroup and a second stage adds the g >> log_ob partials of each
+// block.  When every block has ONE workgroup (the small passes: 2^16 -> 2^8 entries, 2^24 -> 2^16 with 256 blocks ...) its partial IS the
+// block's sum: the workgroups store straight into `out` and the second-stage launch (4 us on the critical path of a latency-bound pass)
+// is dropped.
+static inline void* sums_target(int g, int log_ob, void* partials, void* out) { return (g >> log_ob) == 1 ? out : partials; }
+static void reduce_groups_unless_single(int g, int log_ob, const void* partials, void* out, hipStream_t st) {
+    if ((g >> log_ob) > 1) hipLaunchKernelGGL(k_reduce_groups, dim3(1 << log_ob), dim3(kThreads), 0, st, (const fq*)partials, g >> log_ob, (fq*)out);
+}
 int launch_block_sums(const void* T, size_t L, int log_ob, void* partials, void* out, hipStream_t st, const DmaGates& gates) {
     const size_t Lb0 = L >> log_ob;
     // large tables: LDS-DMA stream with the nt policy, 6.7 vs 6.1 TB/s at 2^28 entries; it wins from 2^27 entries
@@ -751,44 +759,44 @@ int launch_block_sums(const void* T, size_t L, int log_ob, void* partials, void*
     if (Lb0 % 64 == 0 && gates.sums_from_log < 63 && L >= ((size_t)1 << std::max(gates.sums_from_log, 0))) {
         int g = grid_blocks(Lb0 / 64, log_ob);
         g_forms |= kFormSumsDma;
-        hipLaunchKernelGGL((k_block_sums_dma<8, 2>), dim3(g), dim3(kThreads), 0, st, (const fq*)T, L, log_ob, (fq*)partials);
-        hipLaunchKernelGGL(k_reduce_groups, dim3(1 << log_ob), dim3(kThreads), 0, st, (const fq*)partials, g >> log_ob, (fq*)out);
+        hipLaunchKernelGGL((k_block_sums_dma<8, 2>), dim3(g), dim3(kThreads), 0, st, (const fq*)T, L, log_ob, (fq*)sums_target(g, log_ob, partials, out));
+        reduce_groups_unless_single(g, log_ob, partials, out, st);
         return g;
     }
     int g = grid_blocks(L >> log_ob, log_ob);
     g_forms |= kFormSumsReg;
-    hipLaunchKernelGGL(k_block_sums, dim3(g), dim3(kThreads), 0, st, (const fq*)T, L, log_ob, (fq*)partials);
-    hipLaunchKernelGGL(k_reduce_groups, dim3(1 << log_ob), dim3(kThreads), 0, st, (const fq*)partials, g >> log_ob, (fq*)out);
+    hipLaunchKernelGGL(k_block_sums, dim3(g), dim3(kThreads), 0, st, (const fq*)T, L, log_ob, (fq*)sums_target(g, log_ob, partials, out));
+    reduce_groups_unless_single(g, log_ob, partials, out, st);
     return g;
 }
 template <int M>
-static int launch_multifold_m(const void* src, void* dst, size_t Lout, const uint64_t* r, int log_ob, void* partials, hipStream_t st) {
+static int launch_multifold_m(const void* src, void* dst, size_t Lout, const uint64_t* r, int log_ob, void* partials, void* out, hipStream_t st) {
     Chal<M> ch;
     for (int l = 0; l < M; ++l) ch.r[l] = to_fq(r + 4 * l);
     int g = grid_blocks(Lout >> log_ob, log_ob);
-    hipLaunchKernelGGL((k_multifold<M>), dim3(g), dim3(kThreads), 0, st, (const fq*)src, (fq*)dst, Lout, ch, log_ob, (fq*)partials);
+    hipLaunchKernelGGL((k_multifold<M>), dim3(g), dim3(kThreads), 0, st, (const fq*)src, (fq*)dst, Lout, ch, log_ob, (fq*)sums_target(g, log_ob, partials, out));
     return g;
 }
 template <int M, int G>
-static int launch_multifold_lazy_m(const void* src, void* dst, size_t Lout, const uint32_t* w28, int log_ob, void* partials, hipStream_t st) {
+static int launch_multifold_lazy_m(const void* src, void* dst, size_t Lout, const uint32_t* w28, int log_ob, void* partials, void* out, hipStream_t st) {
     W28<M> W;
     for (int b = 0; b < (1 << M); ++b)
         for (int j = 0; j < 10; ++j) W.w[b][j] = w28[b * 10 + j];
     int g = grid_blocks(Lout >> log_ob, log_ob);
-    hipLaunchKernelGGL((k_multifold_lazy<M, G>), dim3(g), dim3(kThreads), 0, st, (const fq*)src, (fq*)dst, Lout, W, log_ob, (fq*)partials);
+    hipLaunchKernelGGL((k_multifold_lazy<M, G>), dim3(g), dim3(kThreads), 0, st, (const fq*)src, (fq*)dst, Lout, W, log_ob, (fq*)sums_target(g, log_ob, partials, out));
     return g;
 }
 int launch_multifold_lazy(int m, const void* src, void* dst, size_t Lout, const uint32_t* w28, int log_ob, void* partials, void* out,
                           hipStream_t st) {
     int g = 0;
     switch (m) {
-        case 1: g = launch_multifold_lazy_m<1, 2>(src, dst, Lout, w28, log_ob, partials, st); break;
-        case 2: g = launch_multifold_lazy_m<2, 4>(src, dst, Lout, w28, log_ob, partials, st); break;
-        case 3: g = launch_multifold_lazy_m<3, 4>(src, dst, Lout, w28, log_ob, partials, st); break;
-        case 4: g = launch_multifold_lazy_m<4, 4>(src, dst, Lout, w28, log_ob, partials, st); break;
+        case 1: g = launch_multifold_lazy_m<1, 2>(src, dst, Lout, w28, log_ob, partials, out, st); break;
+        case 2: g = launch_multifold_lazy_m<2, 4>(src, dst, Lout, w28, log_ob, partials, out, st); break;
+        case 3: g = launch_multifold_lazy_m<3, 4>(src, dst, Lout, w28, log_ob, partials, out, st); break;
+        case 4: g = launch_multifold_lazy_m<4, 4>(src, dst, Lout, w28, log_ob, partials, out, st); break;
         default: return -1;
     }
-    hipLaunchKernelGGL(k_reduce_groups, dim3(1 << log_ob), dim3(kThreads), 0, st, (const fq*)partials, g >> log_ob, (fq*)out);
+    reduce_groups_unless_single(g, log_ob, partials, out, st);
     return g;
 }
 int launch_multifold_wide(int m, const void* src, void* dst, size_t Lout, const uint64_t* r, const uint64_t two24[4], void* wbuf,
@@ -804,8 +812,8 @@ int launch_multifold_wide(int m, const void* src, void* dst, size_t Lout, const 
         if (per < 1) per = 1;
         const int g = (int)(per << log_ob);
         g_forms |= kFormCoop;
-        hipLaunchKernelGGL(k_multifold_coop, dim3(g), dim3(kThreads), 0, st, (const fq*)src, (fq*)dst, Lout, ch, m, log_ob, (fq*)partials);
-        hipLaunchKernelGGL(k_reduce_groups, dim3(1 << log_ob), dim3(kThreads), 0, st, (const fq*)partials, g >> log_ob, (fq*)out);
+        hipLaunchKernelGGL(k_multifold_coop, dim3(g), dim3(kThreads), 0, st, (const fq*)src, (fq*)dst, Lout, ch, m, log_ob, (fq*)sums_target(g, log_ob, partials, out));
+        reduce_groups_unless_single(g, log_ob, partials, out, st);
         return g;
     }
     // small outputs, and blocks that are not whole 64-entry rows (the LDS-DMA form needs them): weights per workgroup in LDS
@@ -813,8 +821,8 @@ int launch_multifold_wide(int m, const void* src, void* dst, size_t Lout, const 
     if (!rows || (lds_below_log > 0 && (lds_below_log >= 63 || Lout < ((size_t)1 << lds_below_log)))) {
         int g = grid_blocks(Lout >> log_ob, log_ob);
         g_forms |= kFormWideLds;
-        hipLaunchKernelGGL(k_multifold_wide_lds, dim3(g), dim3(kThreads), 0, st, (const fq*)src, (fq*)dst, Lout, ch, m, log_ob, (fq*)partials);
-        hipLaunchKernelGGL(k_reduce_groups, dim3(1 << log_ob), dim3(kThreads), 0, st, (const fq*)partials, g >> log_ob, (fq*)out);
+        hipLaunchKernelGGL(k_multifold_wide_lds, dim3(g), dim3(kThreads), 0, st, (const fq*)src, (fq*)dst, Lout, ch, m, log_ob, (fq*)sums_target(g, log_ob, partials, out));
+        reduce_groups_unless_single(g, log_ob, partials, out, st);
         return g;
     }
     if (gates.wide_mfma_from_log < 63 && Lout >= ((size_t)1 << std::max(gates.wide_mfma_from_log, 0))) {
@@ -828,7 +836,7 @@ int launch_multifold_wide(int m, const void* src, void* dst, size_t Lout, const 
         g_forms |= kFormWideMfma;
 #define ZK_MFMA_LAUNCH(BIGV, KV)                                                                                                        \
     hipLaunchKernelGGL((k_multifold_wide_mfma<BIGV, KV>), dim3(g), dim3(kThreads), 0, st, (const fq*)src, (fq*)dst, Lout, (const u32x4*)wbuf, m, \
-                       log_ob, kfix, (fq*)partials)
+                       log_ob, kfix, (fq*)sums_target(g, log_ob, partials, out))
         const int depth = gates.wide_mfma_depth;
         if (stream_stores) {
             if (depth == 2) ZK_MFMA_LAUNCH(true, 2); else if (depth == 3) ZK_MFMA_LAUNCH(true, 3); else ZK_MFMA_LAUNCH(true, 4);
@@ -836,7 +844,7 @@ int launch_multifold_wide(int m, const void* src, void* dst, size_t Lout, const 
             if (depth == 2) ZK_MFMA_LAUNCH(false, 2); else if (depth == 3) ZK_MFMA_LAUNCH(false, 3); else ZK_MFMA_LAUNCH(false, 4);
         }
 #undef ZK_MFMA_LAUNCH
-        hipLaunchKernelGGL(k_reduce_groups, dim3(1 << log_ob), dim3(kThreads), 0, st, (const fq*)partials, g >> log_ob, (fq*)out);
+        reduce_groups_unless_single(g, log_ob, partials, out, st);
         return g;
     }
     // LDS-DMA streams (every large pass): 5.9 vs 5.5 TB/s for register loads at 2^28 entries; ring depth 3, 4, 6 alike.  The eq
@@ -850,23 +858,23 @@ int launch_multifold_wide(int m, const void* src, void* dst, size_t Lout, const 
     g_forms |= stream_stores ? kFormWideDmaStream : kFormWideDma;
     if (stream_stores)
         hipLaunchKernelGGL((k_multifold_wide_dma<true, 4>), dim3(g), dim3(kThreads), 0, st, (const fq*)src, (fq*)dst, Lout, (const u32*)wbuf, m, log_ob,
-                           (fq*)partials);
+                           (fq*)sums_target(g, log_ob, partials, out));
     else
         hipLaunchKernelGGL((k_multifold_wide_dma<false, 4>), dim3(g), dim3(kThreads), 0, st, (const fq*)src, (fq*)dst, Lout, (const u32*)wbuf, m, log_ob,
-                           (fq*)partials);
-    hipLaunchKernelGGL(k_reduce_groups, dim3(1 << log_ob), dim3(kThreads), 0, st, (const fq*)partials, g >> log_ob, (fq*)out);
+                           (fq*)sums_target(g, log_ob, partials, out));
+    reduce_groups_unless_single(g, log_ob, partials, out, st);
     return g;
 }
 int launch_multifold(int m, const void* src, void* dst, size_t Lout, const uint64_t* r, int log_ob, void* partials, void* out, hipStream_t st) {
     int g = 0;
     switch (m) {
-        case 1: g = launch_multifold_m<1>(src, dst, Lout, r, log_ob, partials, st); break;
-        case 2: g = launch_multifold_m<2>(src, dst, Lout, r, log_ob, partials, st); break;
-        case 3: g = launch_multifold_m<3>(src, dst, Lout, r, log_ob, partials, st); break;
-        case 4: g = launch_multifold_m<4>(src, dst, Lout, r, log_ob, partials, st); break;
+        case 1: g = launch_multifold_m<1>(src, dst, Lout, r, log_ob, partials, out, st); break;
+        case 2: g = launch_multifold_m<2>(src, dst, Lout, r, log_ob, partials, out, st); break;
+        case 3: g = launch_multifold_m<3>(src, dst, Lout, r, log_ob, partials, out, st); break;
+        case 4: g = launch_multifold_m<4>(src, dst, Lout, r, log_ob, partials, out, st); break;
         default: return -1;
     }
-    hipLaunchKernelGGL(k_reduce_groups, dim3(1 << log_ob), dim3(kThreads), 0, st, (const fq*)partials, g >> log_ob, (fq*)out);
+    reduce_groups_unless_single(g, log_ob, partials, out, st);
     return g;
 }
 void launch_fold_var(const void* src, void* dst, size_t n_out, int log_s, const uint64_t r[4], hipStream_t st) {
