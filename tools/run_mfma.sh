@@ -1,11 +1,11 @@
+#!/bin/bash
+# threshold of the matrix-core nine-sum sweep: gpurun -- 'bash tools/run_mfma.sh'
 set -o pipefail
+LABEL=run_mfma
+. tools/lib.sh
 B="python -u bench.py --workload sum2x2 --no-extra --no-cpu-baseline --steps 5 --warmup 2"
 for n in 26 24 22; do
 for cfg in "--deg2-mfma-from 64" "--deg2-mfma-from 24" "--deg2-mfma-from 22" "--deg2-mfma-from 20" "--deg2-mfma-from 18"; do
   echo "== 4x2^$n $cfg"
-  timeout -k 10 120 $B --log-n $n $cfg 2>/dev/null | python3 -c "
-import json,sys
-d=json.loads(sys.stdin.read())
-print('prove_ms', round(d['ms_per_step'],4), {k:(v['launches'], round(v['total_ms']/5,4), round(v['achieved_GBs'],0)) for k,v in d['kernels'].items()})
-" || exit 1
+  bench_json 120 $B --log-n $n $cfg | summ_deg2 || exit 1
 done; done
