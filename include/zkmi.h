@@ -407,6 +407,11 @@ int zk_ctx_set_deg2_fold3_fused(zk_ctx *ctx, int dma_slots);
  * (prover.rs:131-139, twice) and the nine sums of its result (the next two rounds' prover.rs:89-107) are one kernel -- GKR layer
  * tables are cache-resident and a pass is bound by launches and per-lane chains, not by bytes.  Proof bytes do not depend on it. */
 int zk_ctx_set_deg2_fused(zk_ctx *ctx, int below_log);
+/* Degree-2 prover, THREE rounds per pass on small tables: while the folded tables have fewer than 2^below_log entries (default 20; 0 = never) a
+ * pass folds the variables of the rounds just run (prover.rs:131-139) and forms the 27 sums that determine the next three round
+ * polynomials (prover.rs:89-107, three times) in one kernel -- a pass on a cache-resident table costs its host round trip, so it
+ * should serve as many rounds as one launch can.  No counterpart in the reference; proof bytes do not depend on it. */
+int zk_ctx_set_deg2_small_triple(zk_ctx *ctx, int below_log);
 enum { ZK_K_BLOCK_SUMS = 0, ZK_K_MULTIFOLD = 1, ZK_K_FOLD = 2, ZK_K_EVAL3 = 3, ZK_K_FOLD4_EVAL3 = 4, ZK_K_SUM9 = 5, ZK_K_FOLD2X4_SUM9 = 6, ZK_K_MULTIFOLD_WIDE = 7, ZK_K_MULTIFOLD_TAIL = 8,
        ZK_K_COUNT = 10 };
 /* per-kernel HIP-event timing of the launches made by the provers on this context */

@@ -158,6 +158,30 @@ def test_wide_circuit_selfconsistent():
     assert vt.peek_digest() == tr.peek_digest()
 
 
+def test_wide_circuit_proof_does_not_depend_on_the_small_table_schedule():
+    """Three rounds per pass on the layer tables (k_fold_sum27, the default below 2^20 entries) against two rounds per pass
+    (k_fold2_sum9) and against separate fold and sums launches: byte-identical GKR proofs and transcript states."""
+    W, depth = 1 << 13, 2
+    rng = random.Random(21)
+    layers = [[(rng.randrange(W), rng.randrange(W), rng.randrange(2)) for g in range(W)] for _ in range(depth)]
+    inputs = O.gen_table(SEED + 123, 0, W)
+    outs = []
+    for small_triple, fused in ((20, 20), (0, 20), (0, 0)):
+        ctx = zk_amd.Context(0)
+        ctx.set_deg2_small_triple(small_triple)
+        ctx.set_deg2_fused(fused)
+        circuit = mk(layers, ctx)
+        tr = zk_amd.Transcript()
+        ctx.forms_used()
+        proof = GKRProver.generate_proof(circuit, tr, inputs)
+        forms = ctx.forms_used()
+        assert ("fold_sum27" in forms) == (small_triple > 0), forms
+        outs.append((np.concatenate([p.round_polys.reshape(-1, 4) for p in proof.sumcheck_proofs]), np.asarray(proof.output_poly),
+                     np.asarray(proof.w_polys_evals), tr.peek_digest()))
+    for o in outs[1:]:
+        assert np.array_equal(o[0], outs[0][0]) and np.array_equal(o[1], outs[0][1]) and np.array_equal(o[2], outs[0][2]) and o[3] == outs[0][3]
+
+
 # ---------------------------------------------------------------- verifier (gkr/src/verifier.rs:21-119)
 def test_verifier_accepts_and_rejects_like_the_oracle():        # gkr_protocol.rs:126-142
     ctx = zk_amd.default_context()

@@ -320,6 +320,7 @@ def test_sum2x2_both_schedules_give_the_oracle_proof(rounds_per_pass, lazy_from)
     c.set_deg2_rounds_per_pass(rounds_per_pass)
     c.set_deg2_lazy_sums(lazy_from)
     c.set_deg2_fused(0)        # every sweep through the nine-sum kernel under test (the fused form has its own test)
+    c.set_deg2_small_triple(0)
     for log_n in (2, 3, 6, 7, 8, 9, 11, 12, 14, 17):
         n = 1 << log_n
         tabs = [O.gen_table(SEED + 90 + k, 0, n) for k in range(4)]
@@ -410,6 +411,7 @@ def test_sum2x2_dma_two_variable_fold_vs_oracle(log_n, stream_stores, lazy_from)
     c.set_dma_gates(27, 0 if stream_stores else 64, 0)
     c.set_deg2_lazy_sums(lazy_from)
     c.set_deg2_fused(0)        # separate fold and sums launches: the forms under test
+    c.set_deg2_small_triple(0)
     n = 1 << log_n
     tabs = [O.gen_table(SEED + 180 + k, 0, n) for k in range(4)]
     m = [MLE(t, ctx=c) for t in tabs]
@@ -568,6 +570,7 @@ def test_sum2x2_mfma_nine_sums_vs_oracle(log_n):
     c = zk_amd.Context(0)
     c.set_deg2_mfma_sums(0)   # every sweep whose quarter-tables are whole 64-entry rows
     c.set_deg2_fused(0)
+    c.set_deg2_small_triple(0)
     n = 1 << log_n
     tabs = [O.gen_table(SEED + 220 + k, 0, n) for k in range(4)]
     m = [MLE(t, ctx=c) for t in tabs]
@@ -590,6 +593,7 @@ def test_sum2x2_fused_fold_and_sums_vs_oracle(log_n, fused_below):
     c = zk_amd.Context(0)
     c.set_deg2_fused(fused_below)
     c.set_deg2_triple(64, 3)
+    c.set_deg2_small_triple(0)
     n = 1 << log_n
     tabs = [O.gen_table(SEED + 300 + k, 0, n) for k in range(4)]
     m = [MLE(t, ctx=c) for t in tabs]
@@ -601,6 +605,65 @@ def test_sum2x2_fused_fold_and_sums_vs_oracle(log_n, fused_below):
     assert ("fold2_sum9" in forms) == (fused_below == 64 and log_n >= 9), forms
     ocoeffs, och = O.sumcheck_prove_sum([[tabs[0], tabs[1]], [tabs[2], tabs[3]]], O.fq1(5), otr)
     assert np.array_equal(proof.round_polys, ocoeffs), log_n
+    assert np.array_equal(pts, och) and tr.peek_digest() == otr.peek_digest()
+
+
+# ---- three rounds per pass on small tables (k_fold_sum27: fold + the 27 sums of the next three rounds) ---------------------------
+@pytest.mark.parametrize("cross_from", [64, 12])
+@pytest.mark.parametrize("log_n", [7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 18])
+def test_sum2x2_small_tables_three_rounds_per_pass_vs_oracle(log_n, cross_from):
+    """Every pass whose folded tables keep more than 64 entries runs k_fold_sum27 (M = 2 after a nine-sum pass, M = 3 after a 27-sum
+    pass or -- cross_from = 12 -- after a matrix-core cross-sum pass): the host runs three rounds from 27 sums.  Few workgroups leave
+    their shares to the host, more go through k_reduce27.  Same proof bytes as the oracle."""
+    c = zk_amd.Context(0)
+    c.set_deg2_small_triple(62)
+    c.set_deg2_triple(cross_from, 4)
+    n = 1 << log_n
+    tabs = [O.gen_table(SEED + 380 + k, 0, n) for k in range(4)]
+    m = [MLE(t, ctx=c) for t in tabs]
+    f = zk_amd.SumPolynomial([zk_amd.ProductPolynomial(m[:2]), zk_amd.ProductPolynomial(m[2:])])
+    tr, otr = zk_amd.Transcript(), O.OTranscript()
+    c.forms_used()
+    proof, pts = zk_amd.SumcheckProver.generate_proof_for_partial_verify(O.fq1(5), f, tr)
+    forms = c.forms_used()
+    assert ("fold_sum27" in forms) == (log_n >= 9), forms
+    if cross_from == 12 and log_n >= 12:
+        assert "cross64" in forms, forms
+    ocoeffs, och = O.sumcheck_prove_sum([[tabs[0], tabs[1]], [tabs[2], tabs[3]]], O.fq1(5), otr)
+    assert np.array_equal(proof.round_polys, ocoeffs), log_n
+    assert np.array_equal(pts, och) and tr.peek_digest() == otr.peek_digest()
+    for t, src in zip(m, tabs):
+        assert np.array_equal(t.get_evaluation_points(), src)      # the factor tables are left unmodified
+
+
+@pytest.mark.parametrize("fill", ["p-1", "zero", "mixed"])
+def test_sum2x2_small_tables_three_rounds_extreme_values(fill):
+    """k_fold_sum27 on tables of p - 1 (every limb at its bound), of zeros, and a mix: same proof bytes as the oracle."""
+    c = zk_amd.Context(0)
+    c.set_deg2_small_triple(62)
+    c.set_deg2_triple(64, 4)
+    n = 1 << 11
+    # raw Montgomery limbs of value p - 1 (the largest canonical limbs: every radix-2^28 column at its bound)
+    pm1 = np.array([((P - 1) >> (64 * k)) & (2**64 - 1) for k in range(4)], dtype=np.uint64)
+    tabs = []
+    for k in range(4):
+        if fill == "p-1":
+            t = np.tile(pm1, (n, 1))
+        elif fill == "zero":
+            t = np.zeros((n, 4), dtype=np.uint64)
+        else:
+            t = O.gen_table(SEED + 390 + k, 0, n)
+            t[::3] = pm1
+            t[1::5] = 0
+        tabs.append(np.ascontiguousarray(t))
+    m = [MLE(t, ctx=c) for t in tabs]
+    f = zk_amd.SumPolynomial([zk_amd.ProductPolynomial(m[:2]), zk_amd.ProductPolynomial(m[2:])])
+    tr, otr = zk_amd.Transcript(), O.OTranscript()
+    c.forms_used()
+    proof, pts = zk_amd.SumcheckProver.generate_proof_for_partial_verify(O.fq1(5), f, tr)
+    assert "fold_sum27" in c.forms_used()
+    ocoeffs, och = O.sumcheck_prove_sum([[tabs[0], tabs[1]], [tabs[2], tabs[3]]], O.fq1(5), otr)
+    assert np.array_equal(proof.round_polys, ocoeffs)
     assert np.array_equal(pts, och) and tr.peek_digest() == otr.peek_digest()
 
 
@@ -621,7 +684,8 @@ def test_sum2x2_three_rounds_per_pass_vs_oracle(log_n, ring):
     c.forms_used()
     proof, pts = zk_amd.SumcheckProver.generate_proof_for_partial_verify(O.fq1(5), f, tr)
     forms = c.forms_used()
-    assert "cross64" in forms and "fold3_dma" in forms, forms
+    # folds with >= 2^12 outputs per table stream through the LDS-DMA kernel, smaller ones are one launch for all four tables
+    assert "cross64" in forms and "fold3_reg" in forms and ("fold3_dma" in forms) == (log_n >= 15), forms
     ocoeffs, och = O.sumcheck_prove_sum([[tabs[0], tabs[1]], [tabs[2], tabs[3]]], O.fq1(5), otr)
     assert np.array_equal(proof.round_polys, ocoeffs), log_n
     assert np.array_equal(pts, och) and tr.peek_digest() == otr.peek_digest()
@@ -688,6 +752,7 @@ def test_sum2x2_mfma_nine_sums_extreme_bytes(fill):
     c = zk_amd.Context(0)
     c.set_deg2_mfma_sums(0)
     c.set_deg2_fused(0)
+    c.set_deg2_small_triple(0)
     n = 1 << 12
 
     def const_table(raw):

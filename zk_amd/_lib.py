@@ -120,6 +120,7 @@ SYMBOLS = [
     ("zk_ctx_set_deg2_mfma_sums", C.c_int, [_VP, C.c_int]),
     ("zk_ctx_set_deg2_triple", C.c_int, [_VP, C.c_int, C.c_int]),
     ("zk_ctx_set_deg2_fused", C.c_int, [_VP, C.c_int]),
+    ("zk_ctx_set_deg2_small_triple", C.c_int, [_VP, C.c_int]),
     ("zk_ctx_set_deg2_fold3_fused", C.c_int, [_VP, C.c_int]),
     ("zk_ctx_set_validate", C.c_int, [_VP, C.c_int]),
     ("zk_mle_count_noncanonical", C.c_int, [_VP, C.POINTER(C.c_uint64)]),

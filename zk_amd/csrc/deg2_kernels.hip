@@ -1188,6 +1188,21 @@ __global__ void __launch_bounds__(kThreads) k_fold2_tables(Tab4 S, Tab4w D, size
     }
 }
 
+// the same for three variables (eight weights): small tables, one launch for all four
+__global__ void __launch_bounds__(kThreads) k_fold3_tables(Tab4 S, Tab4w D, size_t outlen, W28<3> W) {
+    const fq* __restrict__ src = S.t[blockIdx.y];
+    fq* __restrict__ dst = D.t[blockIdx.y];
+    const size_t stride = (size_t)gridDim.x * kThreads;
+    for (size_t o = (size_t)blockIdx.x * kThreads + threadIdx.x; o < outlen; o += stride) {
+        u64 a28[20];
+#pragma unroll
+        for (int k = 0; k < 20; ++k) a28[k] = 0;
+#pragma unroll
+        for (int b = 0; b < 8; ++b) fq28_mac(a28, fq_load(src + (size_t)b * outlen + o), W.w[b]);
+        fq_store(dst + o, fq28_redc(a28));
+    }
+}
+
 // Small tables (GKR layers: <= 2^20 entries per table, L2-resident): a pass is bound by launch gaps and by each lane's serial chain,
 // not by bytes, so the two-variable fold and the nine sums of its result are ONE kernel.  A wave serves 16 next-level quarter-indices
 // j' of one term with FOUR lanes each: lane (e, jj) folds entry e q' + j' of both factor tables (8 loads, 8 unreduced products, 2
@@ -1279,6 +1294,91 @@ __global__ void __launch_bounds__(kThreads) k_fold2_sum9(Tab4 S, Tab4w D, size_t
         for (int w = 1; w < kThreads / 64; ++w) t = fq_add(t, red[w][threadIdx.x]);
         fq_store(&partials[((size_t)term * gridDim.x + blockIdx.x) * 9 + threadIdx.x], t);
     }
+}
+
+// ---- three rounds per pass on SMALL tables (GKR layers) ---------------------------------------------------------------------
+// A pass on a table of <= 2^16 entries costs its host round trip (~20 us) and each lane's serial chain, so it should serve as many
+// rounds as one chain allows.  For a product term F G and the three top variables, write the value of F "at" a in {0, 1, oo} along
+// a variable as F(0), F(1), F(1) - F(0) (the coefficient of the variable).  The 27 sums
+//   T[9a + 3b + c] = sum over both terms and all j of F[a,b,c; j] * G[a,b,c; j]
+// determine the next THREE round polynomials: per variable P(X) = P[0] + X (P[1] - P[0] - P[oo]) + X^2 P[oo], applied axis by axis
+// (host_round_triple_from_sum27).  The kernel folds M (2 or 3) variables of all four tables and forms the 27 sums of the RESULT:
+// 32 lanes per (term, octet-index j''): lane l < 16 folds entry e q'' + j'' (e = l & 7) of factor l >> 3 (2^M loads, 2^M unreduced
+// products, one reduction), stores it and puts it at slot 9 b1 + 3 b2 + b3 of the octet's 27-slot value table in wave-private LDS;
+// three short steps fill the table's oo slots axis by axis (4, 6, 9 differences per factor, one per lane: 19 subtractions per factor
+// instead of 14 per CLASS); lane l < 27 then reads its class's two operands and multiplies ONCE.  Chain per lane: the fold, three
+// subtractions with their LDS round trips, one product -- shorter than k_fold2_sum9's, for three rounds instead of two.
+// partials: [(term * gridDim.x + bx) * 27 + 9a + 3b + c].
+struct Val27 { u32x4 h[2]; };
+__device__ __forceinline__ fq val27_get(const Val27* p) {
+    const u32x4 lo = p->h[0], hi = p->h[1];
+    fq x;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { x.v[k] = lo[k]; x.v[4 + k] = hi[k]; }
+    return x;
+}
+__device__ __forceinline__ void val27_put(Val27* p, const fq& x) {
+    p->h[0] = u32x4{x.v[0], x.v[1], x.v[2], x.v[3]};
+    p->h[1] = u32x4{x.v[4], x.v[5], x.v[6], x.v[7]};
+}
+template <int M>
+__global__ void __launch_bounds__(kThreads) k_fold_sum27(Tab4 S, Tab4w D, size_t outlen, W28<M> W, fq* __restrict__ partials) {
+    __shared__ Val27 val[kThreads / 64][2][2][27]; // [wave][octet of the wave][factor][9a + 3b + c]: 3.4 KiB per wave
+    __shared__ fq red[kThreads / 64][27];
+    const int term = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int o2 = lane >> 5, l = lane & 31;
+    const int fac = (l >> 3) & 1, e = l & 7; // fold role (l < 16)
+    const fq* __restrict__ src = S.t[2 * term + fac];
+    fq* __restrict__ dst = D.t[2 * term + fac];
+    // difference roles: step 1 (third variable, l < 8): pair (b1, b2) = l & 3 of factor l >> 2; step 2 (second variable, l < 12):
+    // (b1, c) = (l % 6) / 3, l % 3 of factor l / 6; step 3 (first variable, l < 18): slot 3b + c = l % 9 of factor l / 9
+    Val27* const v1 = &val[wave][o2][(l >> 2) & 1][9 * ((l >> 1) & 1) + 3 * (l & 1)];
+    Val27* const v2 = &val[wave][o2][l < 6 ? 0 : 1][9 * ((l % 6) / 3) + l % 3];
+    Val27* const v3 = &val[wave][o2][l < 9 ? 0 : 1][l % 9];
+    const int cls = l < 27 ? l : 0;
+    const size_t qn = outlen >> 3; // octet length of the folded tables
+    fq acc = fq_zero();
+    const size_t stride = (size_t)gridDim.x * (kThreads / 32); // octet-indices per grid step
+    for (size_t j0 = (size_t)blockIdx.x * (kThreads / 32) + (size_t)wave * 2; j0 < qn; j0 += stride) { // wave-uniform
+        const size_t j = j0 + o2;
+        const bool live = j < qn;
+        if (l < 16) {
+            const size_t o = (size_t)e * qn + (live ? j : 0);
+            u64 a28[20];
+#pragma unroll
+            for (int k = 0; k < 20; ++k) a28[k] = 0;
+#pragma unroll
+            for (int b = 0; b < (1 << M); ++b) fq28_mac(a28, fq_load(src + (size_t)b * outlen + o), W.w[b]);
+            const fq v = fq28_redc(a28);
+            if (live) fq_store(dst + o, v);
+            val27_put(&val[wave][o2][fac][9 * (e >> 2) + 3 * ((e >> 1) & 1) + (e & 1)], v);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // wave-private table: program order, no barrier
+        if (l < 8) val27_put(v1 + 2, fq_sub(val27_get(v1 + 1), val27_get(v1)));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (l < 12) val27_put(v2 + 6, fq_sub(val27_get(v2 + 3), val27_get(v2)));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (l < 18) val27_put(v3 + 18, fq_sub(val27_get(v3 + 9), val27_get(v3)));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const fq pr = fq_mul(val27_get(&val[wave][o2][0][cls]), val27_get(&val[wave][o2][1][cls]));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // operands in registers before the next trip overwrites the table
+        if (live && l < 27) acc = fq_add(acc, pr);
+    }
+    acc = fq_add(acc, fq_shfl_down(acc, 32)); // the wave's two octets hold the same classes
+    if (lane < 27) red[wave][lane] = acc;
+    __syncthreads();
+    if (threadIdx.x < 27) {
+        fq t = red[0][threadIdx.x];
+#pragma unroll
+        for (int wv = 1; wv < kThreads / 64; ++wv) t = fq_add(t, red[wv][threadIdx.x]);
+        fq_store(&partials[((size_t)term * gridDim.x + blockIdx.x) * 27 + threadIdx.x], t);
+    }
+}
+// second stage: block s adds sum s of `groups` workgroups (fixed order)
+__global__ void __launch_bounds__(kThreads) k_reduce27(const fq* __restrict__ partials, int groups, fq* __restrict__ out) {
+    fq acc[1] = {fq_zero()};
+    for (int i = threadIdx.x; i < groups; i += kThreads) acc[0] = fq_add(acc[0], fq_load(partials + (size_t)i * 27 + blockIdx.x));
+    block_sum_store<1>(acc, out);
 }
 
 // the host tail of the degree-2 prover: four small tables (n entries each) into one contiguous buffer (table-major),
@@ -1433,6 +1533,19 @@ void launch_fold3_tables(const void* const s[4], void* const d[4], size_t outlen
                                (const u32*)wbuf, 3, 0, (fq*)partials);
     }
 }
+void launch_fold3_tables_small(const void* const s[4], void* const d[4], size_t outlen, const uint32_t* w28, hipStream_t st) {
+    Tab4 S;
+    Tab4w D;
+    for (int k = 0; k < 4; ++k) { S.t[k] = (const fq*)s[k]; D.t[k] = (fq*)d[k]; }
+    W28<3> W;
+    for (int b = 0; b < 8; ++b)
+        for (int j = 0; j < 10; ++j) W.w[b][j] = w28[b * 10 + j];
+    size_t gx = (outlen + kThreads - 1) / kThreads;
+    if (gx < 1) gx = 1;
+    if (gx > (size_t)kMaxBlocks) gx = kMaxBlocks;
+    g_forms |= kFormFold3Reg;
+    hipLaunchKernelGGL(k_fold3_tables, dim3((unsigned)gx, 4), dim3(kThreads), 0, st, S, D, outlen, W);
+}
 void launch_gather4(const void* const t[4], size_t n, void* out, hipStream_t st) {
     Tab4 T;
     for (int k = 0; k < 4; ++k) T.t[k] = (const fq*)t[k];
@@ -1495,6 +1608,37 @@ int launch_fold2_sum9(const void* const s[4], void* const d[4], size_t outlen, c
     hipLaunchKernelGGL(k_fold2_sum9, dim3((unsigned)gx, 2), dim3(kThreads), 0, st, S, D, outlen, W, (fq*)partials);
     hipLaunchKernelGGL(k_reduce9, dim3(9), dim3(kThreads), 0, st, (const fq*)partials, (int)gx, 0, (fq*)out);
     return 0;
+}
+
+// launch_fold2_tables / launch_fold3_tables (m = 2 / 3) and the 27 sums of the result for the next THREE rounds in one launch (small
+// tables; outlen a multiple of 16).  Returns G > 0 when `out` holds G workgroups' shares out[g * 27 + i] for the caller to add, 0 when it
+// holds the 27 sums.
+template <int M>
+static int launch_fold_sum27_m(const Tab4& S, const Tab4w& D, size_t outlen, const uint32_t* w28, void* partials, void* out, hipStream_t st,
+                               int host_groups_max) {
+    W28<M> W;
+    for (int b = 0; b < (1 << M); ++b)
+        for (int j = 0; j < 10; ++j) W.w[b][j] = w28[b * 10 + j];
+    size_t gx = (outlen / 8 + kThreads / 32 - 1) / (kThreads / 32);
+    if (gx < 1) gx = 1;
+    if (gx > (size_t)kMaxBlocks9) gx = kMaxBlocks9;
+    g_forms |= kFormFoldSum27;
+    if (2 * gx <= (size_t)host_groups_max) {
+        hipLaunchKernelGGL((k_fold_sum27<M>), dim3((unsigned)gx, 2), dim3(kThreads), 0, st, S, D, outlen, W, (fq*)out);
+        return (int)(2 * gx);
+    }
+    hipLaunchKernelGGL((k_fold_sum27<M>), dim3((unsigned)gx, 2), dim3(kThreads), 0, st, S, D, outlen, W, (fq*)partials);
+    hipLaunchKernelGGL(k_reduce27, dim3(27), dim3(kThreads), 0, st, (const fq*)partials, (int)(2 * gx), (fq*)out);
+    return 0;
+}
+int launch_fold_sum27(int m, const void* const s[4], void* const d[4], size_t outlen, const uint32_t* w28, void* partials, void* out,
+                      hipStream_t st, int host_groups_max) {
+    if ((m != 2 && m != 3) || outlen < 16 || outlen % 16) return -1;
+    Tab4 S;
+    Tab4w D;
+    for (int k = 0; k < 4; ++k) { S.t[k] = (const fq*)s[k]; D.t[k] = (fq*)d[k]; }
+    return m == 2 ? launch_fold_sum27_m<2>(S, D, outlen, w28, partials, out, st, host_groups_max)
+                  : launch_fold_sum27_m<3>(S, D, outlen, w28, partials, out, st, host_groups_max);
 }
 
 } // namespace zkk

@@ -38,6 +38,8 @@ enum Form : unsigned {
     kFormFold3Dma = 1u << 15,     // m = 3 LDS-DMA fold of the degree-2 branch (three rounds per pass)
     kFormFold3Cross64 = 1u << 16, // k_fold3_cross64 (that fold fused with the next level's cross sums)
     kFormFold3Cross64Mfma = 1u << 17, // k_fold3_cross64_mfma (the same sweep with the fold on the matrix cores)
+    kFormFoldSum27 = 1u << 18,    // k_fold_sum27 (small tables: fold + the 27 sums of the next three rounds)
+    kFormFold3Reg = 1u << 19,     // k_fold3_tables (small tables: the three-variable fold of all four tables in one launch)
 };
 extern thread_local unsigned g_forms;
 // Size thresholds of the LDS-DMA forms (log2 of entries; defaults = the measured break-even points)
@@ -51,6 +53,8 @@ struct DmaGates {
     int wide_mfma_depth = 2;       // its pipeline depth K (2..4): table rows of K steps in flight per wave
     int deg2_triple_from_log = 21; // degree-2 prover: three rounds per pass (k_cross64_mfma + m = 3 fold) on tables of >= 2^k entries; 64 = never
     int deg2_fused_below_log = 20; // degree-2 prover: fold + nine sums in one kernel (k_fold2_sum9) for folded tables below 2^k entries; 0 = never
+    int deg2_sum27_below_log = 20; // degree-2 prover: THREE rounds per pass on small tables too (k_fold_sum27) while the folded tables have fewer
+                                   // than 2^k entries; 0 = never (measured: 4 x 2^16 .. 2^24 proves 4-14 % faster with 20, 21 slower at 2^23)
     int deg2_fold3_fused = 8;      // three-round passes: fold fused with the next level's cross sums; 8 = the fold on the matrix cores too
                                    // (k_fold3_cross64_mfma, ring of 4 steps; 12..14: 2..4 steps), 3..5 = DMA slots per wave of the VALU-fold form (k_fold3_cross64), 0 = off
     int deg2_triple_ring = 4;      // its LDS ring: 3 or 4 tiles of 32 KiB
@@ -105,12 +109,19 @@ void launch_cross64(const void* const t[4], size_t q, int ring, void* partials, 
 // multiple of 64); wbuf (>= 80 u32) and partials (>= 1024 elements) are scratch
 void launch_fold3_tables(const void* const s[4], void* const d[4], size_t outlen, const uint64_t* r3, const uint64_t two24[4], void* wbuf,
                          void* partials, hipStream_t st, const DmaGates& gates = DmaGates());
+// the three-variable fold of all four tables in ONE launch with the eight eq weights as kernel arguments (w28: 8 x 10 limbs): any outlen >= 1
+void launch_fold3_tables_small(const void* const s[4], void* const d[4], size_t outlen, const uint32_t* w28, hipStream_t st);
 // launch_fold2_tables followed by launch_sum9 on its result, as one kernel + the second stage (small, cache-resident tables; outlen >= 4)
 // Returns 0 when out holds the nine sums.  With at most host_groups_max workgroups in the launch (out must then hold 9 elements per
 // workgroup, normally pinned host memory) there is no second stage: returns G = the number of workgroups, out[g * 9 + s] = workgroup
 // g's share of sum s, and the caller adds the G shares.
 int launch_fold2_sum9(const void* const s[4], void* const d[4], size_t outlen, const uint32_t* w28, void* partials, void* out, hipStream_t st,
                       int host_groups_max = 0);
+// the m-variable fold (m = 2 or 3, w28 = the 2^m eq weights) of all four tables and the 27 sums T[9a + 3b + c] of the RESULT that serve
+// the next THREE rounds (k_fold_sum27: small tables, outlen a multiple of 16).  Returns like launch_fold2_sum9 with 27 elements per
+// workgroup (G > 0: out[g * 27 + i] = workgroup g's share), 0 when out holds the 27 sums, < 0 for a shape it does not take.
+int launch_fold_sum27(int m, const void* const s[4], void* const d[4], size_t outlen, const uint32_t* w28, void* partials, void* out,
+                      hipStream_t st, int host_groups_max = 0);
 // launch_fold3_tables followed by launch_cross64 on d[], in one sweep: the folded tables are not re-read (needs cross64_fits(outlen / 8));
 // ring = LDS-DMA slots per wave (3, 4 or 5)
 void launch_fold3_cross64(const void* const s[4], void* const d[4], size_t outlen, const uint64_t* r3, const uint64_t two24[4], void* wbuf,

@@ -843,6 +843,34 @@ static void host_round_pair_from_sum9(zk_transcript* tr, const Fq S[9], uint64_t
     zkh::store(rs + 4, s2);
 }
 
+// the host part of THREE rounds from the 27 sums T[9a + 3b + c], a, b, c in {0, 1, oo} (deg2_kernels.hip, k_fold_sum27): along each
+// variable the summed product is P(X) = P[0] + X (P[1] - P[0] - P[oo]) + X^2 P[oo].  Round i sums the later variables over {0, 1} and
+// reads ev(0) = A[0], ev(1) = A[1], ev(2) = 2 A[1] - A[0] + 2 A[oo]; binding X = r leaves the same structure one variable shorter.
+// Exact arithmetic: the evaluations are the field elements prover.rs:93-100 sums.
+static void host_round_triple_from_sum27(zk_transcript* tr, const Fq T[27], uint64_t* coeffs_out /* 3 x 3 */, uint64_t rs[12]) {
+    Fq cur[27];
+    for (int i = 0; i < 27; ++i) cur[i] = T[i];
+    int rest = 9; // entries per value of the leading index
+    for (int i = 0; i < 3; ++i) {
+        Fq A[3];
+        for (int a = 0; a < 3; ++a) {
+            Fq acc = zkh::zero();
+            for (int idx = 0; idx < rest; ++idx)
+                if (idx % 3 != 2 && (idx / 3) % 3 != 2) acc = zkh::add(acc, cur[a * rest + idx]); // later variables over {0, 1}
+            A[a] = acc;
+        }
+        const Fq ev[3] = {A[0], A[1], zkh::add(zkh::sub(zkh::add(A[1], A[1]), A[0]), zkh::add(A[2], A[2]))};
+        const Fq r = host_round_deg2(tr, ev, coeffs_out + 12 * i);
+        zkh::store(rs + 4 * i, r);
+        const Fq r2 = zkh::mul(r, r);
+        for (int idx = 0; idx < rest; ++idx) {
+            const Fq p0 = cur[idx], p1 = cur[rest + idx], pi = cur[2 * rest + idx];
+            cur[idx] = zkh::add(zkh::add(p0, zkh::mul(r, zkh::sub(zkh::sub(p1, p0), pi))), zkh::mul(r2, pi));
+        }
+        rest /= 3;
+    }
+}
+
 // the host part of K rounds from the cross sums P[term][e][e'] = sum_j F_e[j] G_e'[j] (e, e' < 2^K index the K top variables, the
 // first to bind on the most significant bit; deg2_kernels.hip, k_cross64_mfma).  With x the point of the K variables,
 // sum_j F(x, j) G(x, j) = sum_{e,e'} eq(x, e) eq(x, e') P[e][e'], so round i (r_0..r_{i-1} bound, X free, the rest y boolean) reads
@@ -908,8 +936,10 @@ static int prove_sum2x2_pairs(zk_ctx* c, const void* const tables[4], size_t len
     // nine U sums of k_sum9_lazy (kU) -- the last two are finished here on the host instead of by one more small launch
     constexpr int kU = -1;
     int sums_kind = 0;
+    bool have27 = false; // the pinned buffer holds k_fold_sum27's 27 sums (or sums_kind workgroups' shares of them): three rounds
     auto launch_sums = [&](const void* const t[4], size_t n) -> int {
         ProfScope ps(c, ZK_K_SUM9, (uint64_t)n * 32 * 4);
+        have27 = false;
         if (deg2_triple_ok(c, n)) {
             zkk::launch_cross64(t, n / 8, c->gates.deg2_triple_ring, c->partials, c->sums_host_dev, c->stream); // 128 cross sums straight into pinned host memory
             return 3;
@@ -949,7 +979,15 @@ static int prove_sum2x2_pairs(zk_ctx* c, const void* const tables[4], size_t len
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipStreamSynchronize(c->stream));
         uint64_t rs[12];
-        if (K == 3) {
+        if (K == 3 && have27) {
+            Fq T[27];
+            for (int i = 0; i < 27; ++i) {
+                Fq a = zkh::load(c->sums_host + 4 * i);
+                for (int g = 1; g < sums_kind; ++g) a = zkh::add(a, zkh::load(c->sums_host + 4 * ((size_t)g * 27 + i))); // fixed order
+                T[i] = a;
+            }
+            host_round_triple_from_sum27(tr, T, coeffs_out + 12 * k, rs);
+        } else if (K == 3) {
             Fq P[128];
             for (int i = 0; i < 128; ++i) P[i] = zkh::load(c->sums_host + 4 * i);
             host_rounds_from_cross(tr, 3, P, coeffs_out + 12 * k, rs);
@@ -965,8 +1003,17 @@ static int prove_sum2x2_pairs(zk_ctx* c, const void* const tables[4], size_t len
         if ((rc = ensure_work(c, pass & 1, 4 * outlen * kElem))) return rc;
         void* dst[4];
         for (int t = 0; t < 4; ++t) dst[t] = (uint8_t*)c->work[pass & 1] + (size_t)t * outlen * kElem;
-        const int fb = c->gates.deg2_fused_below_log;
-        if (K == 3 && c->gates.deg2_fold3_fused && deg2_triple_ok(c, outlen)) {
+        const int fb = c->gates.deg2_fused_below_log, tb = c->gates.deg2_sum27_below_log;
+        if (tb > 0 && outlen > kHostTail && outlen < ((size_t)1 << std::min(tb, 62)) && !deg2_triple_ok(c, outlen)) {
+            // small tables: the fold of this pass's K variables and the 27 sums that serve the next THREE rounds in one launch
+            ProfScope ps(c, ZK_K_FOLD2X4_SUM9, (uint64_t)curlen * 32 * 4 + (uint64_t)outlen * 32 * 4);
+            uint32_t w28[8 * 10];
+            eq_weights28(rs, (unsigned)K, w28);
+            sums_kind = zkk::launch_fold_sum27(K, cur, dst, outlen, w28, c->partials, c->sums_host_dev, c->stream, kHostSumGroups);
+            if (sums_kind < 0) return ZK_E_ARG;
+            have27 = true;
+            K = 3;
+        } else if (K == 3 && c->gates.deg2_fold3_fused && deg2_triple_ok(c, outlen)) {
             // the next pass serves three rounds too: its cross sums come out of this fold's sweep
             ProfScope ps(c, ZK_K_FOLD2X4_SUM9, (uint64_t)curlen * 32 * 4 + (uint64_t)outlen * 32 * 4);
             zkk::launch_fold3_cross64(cur, dst, outlen, rs, c->two24, c->wide_w, c->gates.deg2_fold3_fused, c->partials, c->sums_host_dev, c->stream,
@@ -980,7 +1027,11 @@ static int prove_sum2x2_pairs(zk_ctx* c, const void* const tables[4], size_t len
         } else {
             {
                 ProfScope ps(c, ZK_K_FOLD2X4_SUM9, (uint64_t)curlen * 32 * 4 + (uint64_t)outlen * 32 * 4);
-                if (K == 3) {
+                if (K == 3 && (outlen < kFold3SmallBelow || outlen % 64)) {
+                    uint32_t w28[8 * 10]; // small tables: one launch, weights as kernel arguments
+                    eq_weights28(rs, 3, w28);
+                    zkk::launch_fold3_tables_small(cur, dst, outlen, w28, c->stream);
+                } else if (K == 3) {
                     zkk::launch_fold3_tables(cur, dst, outlen, rs, c->two24, c->wide_w, c->partials, c->stream, c->gates);
                 } else {
                     uint32_t w28[4 * 10];
@@ -1320,6 +1371,11 @@ int zk_ctx_set_deg2_lazy_sums(zk_ctx* c, int from_log) {
 int zk_ctx_set_deg2_mfma_sums(zk_ctx* c, int from_log) {
     if (!c || from_log < 0 || from_log > 64) return ZK_E_ARG;
     c->gates.sum9_mfma_from_log = from_log;
+    return ZK_OK;
+}
+int zk_ctx_set_deg2_small_triple(zk_ctx* c, int below_log) {
+    if (!c || below_log < 0 || below_log > 62) return ZK_E_ARG;
+    c->gates.deg2_sum27_below_log = below_log;
     return ZK_OK;
 }
 int zk_ctx_set_deg2_fused(zk_ctx* c, int below_log) {

@@ -25,8 +25,9 @@ constexpr size_t kChunkElems = (size_t)1 << 21; // 64 MiB staging chunks for byt
 constexpr size_t kLeChunkElems = (size_t)1 << 19; // to_bytes: 16 MiB halves of the pinned staging buffer
 constexpr size_t kSums = (size_t)1 << zkk::kMaxFoldBatch; // block sums per pass
 constexpr size_t kHostTail = 64;                // degree-2 prover: tables of <= this many entries are finished on the host
+constexpr size_t kFold3SmallBelow = (size_t)1 << 12; // degree-2 prover: three-variable folds with fewer outputs per table run as one launch (k_fold3_tables)
 constexpr int kHostSumGroups = 32;              // fold + nine-sum passes of <= this many workgroups leave their partial sums to the host
-constexpr size_t kHostStage = 9 * kHostSumGroups; // elements of the pinned staging buffer (>= 4 * kHostTail)
+constexpr size_t kHostStage = 27 * kHostSumGroups; // elements of the pinned staging buffer (>= 4 * kHostTail): 27 sums per workgroup of k_fold_sum27
 static_assert(kHostStage >= 4 * kHostTail, "the staging buffer receives the four tail tables");
 static_assert(kHostStage >= kSums, "the staging buffer also receives the block sums of a pass");
 
