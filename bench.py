@@ -46,6 +46,7 @@ def parse(argv=None):
     ap.add_argument("--no-absorb", action="store_true", help="skip the one-off 32*N-byte Keccak table absorb")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra workloads (size sweep, degree 2, GKR) of the single-GPU line")
+    ap.add_argument("--no-live-traffic", action="store_true", help="skip the two rocprofv3 counter passes (child runs of this command, one step each) that fill roofline.traffic")
     ap.add_argument("--cpu-log-n", type=int, default=24, help="bounded CPU sample size (2^k entries)")
     ap.add_argument("--cpu-full-log", type=int, default=None, help="one more CPU sample at 2^k entries (SURVEY 8d: 2^28 once; tens of seconds, ~26 GiB)")
     ap.add_argument("--fold-batch", type=int, default=0, help="rounds bound per device pass (0 = library default)")
@@ -239,6 +240,11 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: the line would be mislabelled")
 
+    # roofline.traffic: the HBM counter passes run as CHILD processes before this one touches the GPU
+    live_traffic = None
+    if world == 1 and not args.force_sharded and args.workload in ("mle", "sum2x2") and not args.no_live_traffic:
+        live_traffic = live_pmc_traffic(args)
+
     # stdout carries exactly ONE JSON line: libraries (RCCL prints a version banner on fd 1) write to stderr instead
     sys.stdout.flush()
     json_fd = os.dup(1)
@@ -286,6 +292,8 @@ def main():
             emit(bench_gkr(args, ctx, zk_amd, np, args.gkr_depth, args.gkr_log_width, args.steps, args.warmup))
             return
         result = bench_single(args, ctx, zk_amd, np, args.workload, args.log_n, args.steps, args.warmup, absorb=not args.no_absorb)
+        if live_traffic is not None:
+            attach_live_traffic(result["roofline"], result.get("kernels", {}), live_traffic)
         if not args.no_extra:
             result["extra"] = extra_workloads(args, ctx, zk_amd, np, torch)
 
@@ -492,7 +500,7 @@ def bench_single(args, ctx, zk_amd, np, workload, log_n, steps, warmup, absorb=F
     roofline = {
         "bound": "hbm", "kernel": kernel, "achieved": dom["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": dom["achieved_GBs"] / HBM_PEAK_GBS,
-        # PMC counters cannot be read from inside the process: null here, and the committed rocprofv3 passes of this same command named beside it
+        # filled by attach_live_traffic from this run's own counter passes (child processes); null with the committed passes named beside it otherwise
         "traffic": None, "traffic_source": pmc_traffic(kernel, log_n) if workload == "mle" else None,
         "note": "achieved = algorithmic bytes of all launches of the kernel in the timed steps / their summed "
                 "HIP-event durations on the context's stream (multifold / multifold_wide: 32 B per input entry read + 32 B per output entry written; "
@@ -811,6 +819,70 @@ def bench_gkr(args, ctx, zk_amd, np, depth, k, steps, warmup):
         "note": "prove_ms includes the reference's serial Keccak absorb of the 2^k-entry output layer (prover.rs:46, "
                 "output_absorb_ms); the layer sumchecks are latency-bound: 2*k_in sequential rounds per layer, each kernel + 96-byte D2H + host Keccak; tables are "
                 "2^k_in entries (32 MiB at k = 20), far below the HBM roofline regime",
+    }
+
+
+def live_pmc_traffic(args):
+    """HBM bytes of this very command from the PMC counters, collected as /opt/skills/guides/MI355X_MICROARCH.md prescribes: two
+    SEPARATE rocprofv3 passes (--pmc FETCH_SIZE, then --pmc WRITE_SIZE; no tracing options beside them), each a child run of
+    `python3 bench.py <same flags> --steps 1 --warmup 1` without the CPU legs, started before this process initialises the GPU.
+    Returns tools/prof_summary.py's per-kernel dictionary, or {"error": reason}: the line then keeps traffic = null and names the
+    committed counter file instead.  Every failure mode ends the attempt (time limit with SIGKILL, non-zero exit, no CSV)."""
+    import shutil
+    import subprocess
+    import tempfile
+
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return {"error": "rocprofv3 not found"}
+    if not os.path.exists("/dev/kfd"):
+        return {"error": "no GPU device node (/dev/kfd)"}
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        import prof_summary
+    except ImportError as e:
+        return {"error": f"tools/prof_summary.py: {e}"}
+    child = ["python3", os.path.abspath(__file__)] + sys.argv[1:] + ["--no-absorb", "--no-cpu-baseline", "--no-extra", "--no-live-traffic", "--steps", "1", "--warmup", "1"]
+    env = dict(os.environ, TMPDIR="/tmp")
+    t0 = time.perf_counter()
+    with tempfile.TemporaryDirectory(prefix="zk_pmc_", dir="/tmp") as tmp:
+        dirs = {}
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            cmd = ["timeout", "-s", "KILL", "180", prof, "--pmc", counter, "--output-format", "csv", "-d", d, "--"] + child
+            try:
+                r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=200)
+            except (OSError, subprocess.TimeoutExpired) as e:
+                return {"error": f"{counter} pass: {type(e).__name__}: {e}"}
+            if r.returncode != 0:
+                return {"error": f"{counter} pass: exit {r.returncode}: " + r.stderr.decode(errors="replace")[-300:]}
+            dirs[counter] = d
+        try:
+            out = prof_summary.traffic_dict(dirs["FETCH_SIZE"], dirs["WRITE_SIZE"], args.log_n)
+        except (SystemExit, Exception) as e:  # no CSV under the output directory, or a column missing
+            return {"error": f"counter CSV: {e}"}
+    out["seconds"] = time.perf_counter() - t0
+    out["command"] = "rocprofv3 --pmc <FETCH_SIZE | WRITE_SIZE> -- " + " ".join(child[:1] + ["bench.py"] + child[2:])
+    return out
+
+
+def attach_live_traffic(roofline, kernels, live):
+    """roofline.traffic = HBM bytes per launch of the dominant kernel from THIS run's counter passes (read = 2 x FETCH_SIZE KiB,
+    write = WRITE_SIZE KiB: the guide's gfx950 correction), next to the algorithmic bytes per launch `achieved` is priced on."""
+    if "error" in live:
+        roofline["traffic_note"] = "live counter passes failed (" + live["error"] + "); traffic_source names the committed passes of this command"
+        return
+    k = live["kernels"].get(roofline["kernel"])
+    if not k or not k["launches"]:
+        roofline["traffic_note"] = "live counter passes hold no launch of " + roofline["kernel"]
+        return
+    roofline["traffic"] = k["bytes_per_launch"]
+    alg = kernels.get(roofline["kernel"], {}).get("alg_bytes_per_launch")
+    roofline["traffic_source"] = {
+        "live": True, "command": live["command"], "seconds": round(live["seconds"], 1), "correction": live["correction"],
+        "launches_counted": k["launches"], "read_bytes_per_launch": k["read_bytes"] / k["launches"], "write_bytes_per_launch": k["write_bytes"] / k["launches"],
+        "algorithmic_bytes_per_launch": alg, "traffic_over_algorithmic": (k["bytes_per_launch"] / alg) if alg else None,
+        "all_kernels": {n: v["bytes_per_launch"] for n, v in live["kernels"].items()},
     }
 
 

@@ -55,7 +55,15 @@ def test_gpus_1_line_has_the_contract_keys():
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
               "config", "roofline", "cpu_baseline"):
         assert k in d, k
-    assert d["n_gpus"] == 1 and d["vs_baseline"] is None and d["roofline"]["traffic"] is None
+    assert d["n_gpus"] == 1 and d["vs_baseline"] is None
+    # roofline.traffic: this run's own two rocprofv3 counter passes (child processes), or null with the reason beside it
+    rf = d["roofline"]
+    if rf["traffic"] is None:
+        assert "traffic_note" in rf, rf
+    else:
+        src = rf["traffic_source"]
+        assert src["live"] is True and rf["traffic"] > 0 and src["launches_counted"] > 0, rf
+        assert abs(src["read_bytes_per_launch"] + src["write_bytes_per_launch"] - rf["traffic"]) <= 1e-6 * rf["traffic"]
     assert 0 < d["roofline"]["frac"] < 1 and d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] == 1
     alu = d["int32_alu"]
     assert alu["peak_lane_mads_per_s"] > 1e13

@@ -59,13 +59,13 @@ def pmc(d):
             print(line)
 
 
-def traffic_json(rd_dir, wr_dir, log_n):
-    """HBM bytes per launch of the bench kernels from a FETCH_SIZE pass and a WRITE_SIZE pass -> JSON on stdout
-    (the file bench.py reads for roofline.traffic)."""
-    import json
-
+def traffic_dict(rd_dir, wr_dir, log_n):
+    """HBM bytes per launch of the bench kernels from a FETCH_SIZE pass and a WRITE_SIZE pass (what bench.py reports as
+    roofline.traffic: from its own counter passes when rocprofv3 is there, else from the committed file of the same command)."""
     names = {"k_multifold_lazy": "multifold", "k_multifold": "multifold", "k_multifold_roll": "multifold", "k_multifold_wide": "multifold_wide", "k_multifold_wide_lds": "multifold_wide", "k_multifold_wide_dma": "multifold_wide", "k_multifold_wide_mfma": "multifold_wide", "k_block_sums_dma": "block_sums", "k_multifold_coop": "multifold_tail", "k_block_sums": "block_sums",
-             "k_sum9": "sum9", "k_fold2_tables": "fold2x4_sum9", "k_eval3": "eval3", "k_fold4_eval3": "fold4_eval3"}
+             "k_sum9": "sum9", "k_sum9_lazy": "sum9", "k_sum9_mfma": "sum9", "k_sum16_mfma": "sum9", "k_cross64_mfma": "sum9", "k_fold2_tables": "fold2x4_sum9", "k_fold2_tables_dma": "fold2x4_sum9",
+             "k_fold3_tables_dma": "fold2x4_sum9", "k_fold3_tables": "fold2x4_sum9", "k_fold2_sum9": "fold2x4_sum9", "k_fold_sum27": "fold2x4_sum9", "k_fold3_cross64": "fold2x4_sum9",
+             "k_fold3_cross64_mfma": "fold2x4_sum9", "k_eval3": "eval3", "k_fold4_eval3": "fold4_eval3"}
     acc = defaultdict(lambda: {"launches": 0, "read_bytes": 0.0, "write_bytes": 0.0})
     for d, counter, key, scale in ((rd_dir, "FETCH_SIZE", "read_bytes", 2 * 1024.0), (wr_dir, "WRITE_SIZE", "write_bytes", 1024.0)):
         for f in find(d, "_counter_collection.csv"):
@@ -80,10 +80,16 @@ def traffic_json(rd_dir, wr_dir, log_n):
                         a["launches"] += 1
     for a in acc.values():
         a["bytes_per_launch"] = (a["read_bytes"] + a["write_bytes"]) / max(a["launches"], 1)
-    print(json.dumps({
+    return {
         "source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) of the bench command; tools/prof_summary.py traffic",
         "correction": "HBM read bytes = 2 * FETCH_SIZE KiB * 1024 (gfx950, 16 B/lane streams); write bytes = WRITE_SIZE KiB * 1024",
-        "log_n": int(log_n), "kernels": dict(acc)}, indent=1))
+        "log_n": int(log_n), "kernels": dict(acc)}
+
+
+def traffic_json(rd_dir, wr_dir, log_n):
+    import json
+
+    print(json.dumps(traffic_dict(rd_dir, wr_dir, log_n), indent=1))
 
 
 if __name__ == "__main__":
