@@ -837,6 +837,8 @@ def live_pmc_traffic(args):
         return {"error": "rocprofv3 not found"}
     if not os.path.exists("/dev/kfd"):
         return {"error": "no GPU device node (/dev/kfd)"}
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return {"error": "this run is itself under a profiler (its preloaded library has initialised the GPU: no child may be started from here)"}
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     try:
         import prof_summary

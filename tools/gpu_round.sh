@@ -8,7 +8,7 @@ TAG=${1:-r02}
 OUT=gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp
-BENCH="bench.py --no-absorb --no-cpu-baseline --no-extra --steps 3 --warmup 1"
+BENCH="bench.py --no-live-traffic --no-absorb --no-cpu-baseline --no-extra --steps 3 --warmup 1"
 
 if [ -z "$PROFILE_ONLY" ]; then
 timeout -k 10 900 python -u -m pytest tests -m gpu -x -q --timeout 300 --timeout-method thread > $OUT/${TAG}_pytest_gpu.log 2>&1 || { tail -30 $OUT/${TAG}_pytest_gpu.log; exit 1; }

@@ -7,7 +7,7 @@ FORM=${2:-8}
 OUT=gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp
-B="bench.py --workload sum2x2 --log-n 26 --no-cpu-baseline --no-extra --steps 3 --warmup 1 --deg2-fold3-fused $FORM"
+B="bench.py --no-live-traffic --workload sum2x2 --log-n 26 --no-cpu-baseline --no-extra --steps 3 --warmup 1 --deg2-fold3-fused $FORM"
 C1="SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_INSTS_SALU SQ_INSTS_VMEM_RD"
 C2="SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC"
 for p in 1 2; do

@@ -8,7 +8,7 @@ OUT=gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp
 rm -rf $OUT/${TAG}_gaps_$LOGN
-timeout -s KILL 200 rocprofv3 --kernel-trace --output-format csv -d $OUT/${TAG}_gaps_$LOGN -- python3 bench.py --log-n $LOGN --no-absorb --no-cpu-baseline --no-extra --steps 20 --warmup 3 > $OUT/${TAG}_gaps_$LOGN.log 2>&1 || { echo "exit $?"; tail -30 $OUT/${TAG}_gaps_$LOGN.log; exit 1; }
+timeout -s KILL 200 rocprofv3 --kernel-trace --output-format csv -d $OUT/${TAG}_gaps_$LOGN -- python3 bench.py --no-live-traffic --log-n $LOGN --no-absorb --no-cpu-baseline --no-extra --steps 20 --warmup 3 > $OUT/${TAG}_gaps_$LOGN.log 2>&1 || { echo "exit $?"; tail -30 $OUT/${TAG}_gaps_$LOGN.log; exit 1; }
 python3 - <<PY > $OUT/${TAG}_gaps_$LOGN.txt
 import csv,glob,re
 f=glob.glob('$OUT/${TAG}_gaps_$LOGN/**/*_kernel_trace.csv',recursive=True)[0]
