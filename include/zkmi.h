@@ -143,6 +143,13 @@ int zk_sumcheck_prove_mle(zk_ctx *ctx, const zk_mle *poly, int absorb_table, zk_
  *   the proof unchecked, as in the reference (:185). */
 int zk_sumcheck_prove_sum2x2(zk_ctx *ctx, zk_mle *const tables[4], const uint64_t claim_mont[4],
                              zk_transcript *transcript, uint64_t *coeffs_out, uint64_t *challenges_out);
+/* The same entry point for SumPolynomial[ ProductPolynomial[f, g], ProductPolynomial[h, ones] ] with `ones` the table of ones of
+ * the same length: the relation f g + h, i.e. both phases of a GKR layer (gkr/src/prover.rs:55-147 builds exactly such four tables).
+ * tables = {f, g, h}.  Byte-identical proofs and transcript to zk_sumcheck_prove_sum2x2 on {f, g, h, ones}; the small-table passes
+ * run in their product-plus-linear form, which never reads the constant factor (see zk_ctx_set_deg2_first_triple).  The table of
+ * ones the general kernels need is allocated and freed inside the call. */
+int zk_sumcheck_prove_prod_plus_linear(zk_ctx *ctx, zk_mle *const tables[3], const uint64_t claim_mont[4],
+                                       zk_transcript *transcript, uint64_t *coeffs_out, uint64_t *challenges_out);
 
 /* ---- the same round loop in steps, for a table sharded over several GPUs ----------------
  * generate_round_polys (sumcheck/src/prover.rs:45-155, MLE branch) cut at the points where ranks
@@ -412,6 +419,13 @@ int zk_ctx_set_deg2_fused(zk_ctx *ctx, int below_log);
  * polynomials (prover.rs:89-107, three times) in one kernel -- a pass on a cache-resident table costs its host round trip, so it
  * should serve as many rounds as one launch can.  No counterpart in the reference; proof bytes do not depend on it. */
 int zk_ctx_set_deg2_small_triple(zk_ctx *ctx, int below_log);
+/* Degree-2 prover, the FIRST pass as 27 sums (three rounds before the first fold, k_fold_sum27<0>) for tables below 2^below_log
+ * entries (default 19; 0 = never: the nine-sum pass serves two rounds).  linear_below_log (default 20) is the same threshold for relations
+ * of the shape F G + H * 1 -- both phases of a GKR layer (gkr/src/prover.rs:55-147 builds them as four dense tables) -- which the GKR
+ * prover runs through the product-plus-linear form of the 27-sum kernels: the constant factor is neither read nor folded and the two
+ * terms share one wave population.  linear_below_log = 0 turns that form off altogether (the general four-table kernels run).  No
+ * counterpart in the reference; proof bytes do not depend on either value. */
+int zk_ctx_set_deg2_first_triple(zk_ctx *ctx, int below_log, int linear_below_log);
 enum { ZK_K_BLOCK_SUMS = 0, ZK_K_MULTIFOLD = 1, ZK_K_FOLD = 2, ZK_K_EVAL3 = 3, ZK_K_FOLD4_EVAL3 = 4, ZK_K_SUM9 = 5, ZK_K_FOLD2X4_SUM9 = 6, ZK_K_MULTIFOLD_WIDE = 7, ZK_K_MULTIFOLD_TAIL = 8,
        ZK_K_COUNT = 10 };
 /* per-kernel HIP-event timing of the launches made by the provers on this context */

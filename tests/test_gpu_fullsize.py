@@ -130,6 +130,7 @@ def test_sum2x2_2pow26_config4_size():
     ctx.set_deg2_triple(64, 4)
     ctx.set_deg2_fused(0)
     ctx.set_deg2_small_triple(0)
+    ctx.set_deg2_first_triple(0, 0)    # first pass: the nine-sum forms this test is about
     ctx.forms_used()
     proof1, pts1 = zk_amd.SumcheckProver.generate_proof_for_partial_verify(O.fq1(0), f, zk_amd.Transcript())
     assert "cross64" not in ctx.forms_used()

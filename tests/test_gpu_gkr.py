@@ -159,23 +159,25 @@ def test_wide_circuit_selfconsistent():
 
 
 def test_wide_circuit_proof_does_not_depend_on_the_small_table_schedule():
-    """Three rounds per pass on the layer tables (k_fold_sum27, the default below 2^20 entries) against two rounds per pass
-    (k_fold2_sum9) and against separate fold and sums launches: byte-identical GKR proofs and transcript states."""
+    """Three rounds per pass on the layer tables (k_fold_sum27, the default below 2^20 entries; in its product-plus-linear form
+    P W + Q * 1, the default of the GKR prover, and in the general four-table form) against two rounds per pass (k_fold2_sum9) and
+    against separate fold and sums launches: byte-identical GKR proofs and transcript states."""
     W, depth = 1 << 13, 2
     rng = random.Random(21)
     layers = [[(rng.randrange(W), rng.randrange(W), rng.randrange(2)) for g in range(W)] for _ in range(depth)]
     inputs = O.gen_table(SEED + 123, 0, W)
     outs = []
-    for small_triple, fused in ((20, 20), (0, 20), (0, 0)):
+    for small_triple, fused, linear in ((20, 20, 21), (20, 20, 0), (0, 20, 21), (0, 20, 0), (0, 0, 0)):
         ctx = zk_amd.Context(0)
         ctx.set_deg2_small_triple(small_triple)
         ctx.set_deg2_fused(fused)
+        ctx.set_deg2_first_triple(0, linear)   # 0: the GKR phases through the general four-table kernels
         circuit = mk(layers, ctx)
         tr = zk_amd.Transcript()
         ctx.forms_used()
         proof = GKRProver.generate_proof(circuit, tr, inputs)
         forms = ctx.forms_used()
-        assert ("fold_sum27" in forms) == (small_triple > 0), forms
+        assert ("fold_sum27" in forms) == (small_triple > 0 or linear > 0) and ("pwq" in forms) == (linear > 0), forms
         outs.append((np.concatenate([p.round_polys.reshape(-1, 4) for p in proof.sumcheck_proofs]), np.asarray(proof.output_poly),
                      np.asarray(proof.w_polys_evals), tr.peek_digest()))
     for o in outs[1:]:

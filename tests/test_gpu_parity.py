@@ -321,6 +321,7 @@ def test_sum2x2_both_schedules_give_the_oracle_proof(rounds_per_pass, lazy_from)
     c.set_deg2_lazy_sums(lazy_from)
     c.set_deg2_fused(0)        # every sweep through the nine-sum kernel under test (the fused form has its own test)
     c.set_deg2_small_triple(0)
+    c.set_deg2_first_triple(0, 0)    # first pass: the nine-sum forms this test is about
     for log_n in (2, 3, 6, 7, 8, 9, 11, 12, 14, 17):
         n = 1 << log_n
         tabs = [O.gen_table(SEED + 90 + k, 0, n) for k in range(4)]
@@ -412,6 +413,7 @@ def test_sum2x2_dma_two_variable_fold_vs_oracle(log_n, stream_stores, lazy_from)
     c.set_deg2_lazy_sums(lazy_from)
     c.set_deg2_fused(0)        # separate fold and sums launches: the forms under test
     c.set_deg2_small_triple(0)
+    c.set_deg2_first_triple(0, 0)    # first pass: the nine-sum forms this test is about
     n = 1 << log_n
     tabs = [O.gen_table(SEED + 180 + k, 0, n) for k in range(4)]
     m = [MLE(t, ctx=c) for t in tabs]
@@ -571,6 +573,7 @@ def test_sum2x2_mfma_nine_sums_vs_oracle(log_n):
     c.set_deg2_mfma_sums(0)   # every sweep whose quarter-tables are whole 64-entry rows
     c.set_deg2_fused(0)
     c.set_deg2_small_triple(0)
+    c.set_deg2_first_triple(0, 0)    # first pass: the nine-sum forms this test is about
     n = 1 << log_n
     tabs = [O.gen_table(SEED + 220 + k, 0, n) for k in range(4)]
     m = [MLE(t, ctx=c) for t in tabs]
@@ -594,6 +597,7 @@ def test_sum2x2_fused_fold_and_sums_vs_oracle(log_n, fused_below):
     c.set_deg2_fused(fused_below)
     c.set_deg2_triple(64, 3)
     c.set_deg2_small_triple(0)
+    c.set_deg2_first_triple(0, 0)    # first pass: the nine-sum forms this test is about
     n = 1 << log_n
     tabs = [O.gen_table(SEED + 300 + k, 0, n) for k in range(4)]
     m = [MLE(t, ctx=c) for t in tabs]
@@ -617,6 +621,7 @@ def test_sum2x2_small_tables_three_rounds_per_pass_vs_oracle(log_n, cross_from):
     their shares to the host, more go through k_reduce27.  Same proof bytes as the oracle."""
     c = zk_amd.Context(0)
     c.set_deg2_small_triple(62)
+    c.set_deg2_first_triple(0, 0)    # first pass: the nine-sum forms this test is about
     c.set_deg2_triple(cross_from, 4)
     n = 1 << log_n
     tabs = [O.gen_table(SEED + 380 + k, 0, n) for k in range(4)]
@@ -641,6 +646,7 @@ def test_sum2x2_small_tables_three_rounds_extreme_values(fill):
     """k_fold_sum27 on tables of p - 1 (every limb at its bound), of zeros, and a mix: same proof bytes as the oracle."""
     c = zk_amd.Context(0)
     c.set_deg2_small_triple(62)
+    c.set_deg2_first_triple(0, 0)    # first pass: the nine-sum forms this test is about
     c.set_deg2_triple(64, 4)
     n = 1 << 11
     # raw Montgomery limbs of value p - 1 (the largest canonical limbs: every radix-2^28 column at its bound)
@@ -664,6 +670,90 @@ def test_sum2x2_small_tables_three_rounds_extreme_values(fill):
     assert "fold_sum27" in c.forms_used()
     ocoeffs, och = O.sumcheck_prove_sum([[tabs[0], tabs[1]], [tabs[2], tabs[3]]], O.fq1(5), otr)
     assert np.array_equal(proof.round_polys, ocoeffs)
+    assert np.array_equal(pts, och) and tr.peek_digest() == otr.peek_digest()
+
+
+# ---- the product-plus-linear form F G + H * 1 of the 27-sum passes (the GKR phases) and the first pass as 27 sums ---------------------
+def _ones_table(n):
+    return np.ascontiguousarray(np.tile(O.fq1(1), (n, 1)))   # Montgomery form of 1
+
+
+@pytest.mark.parametrize("mode", ["default", "all27", "off"])
+@pytest.mark.parametrize("log_n", [0, 1, 3, 6, 7, 8, 9, 10, 11, 12, 13, 14, 16, 18])
+def test_prod_plus_linear_vs_oracle(log_n, mode):
+    """zk_sumcheck_prove_prod_plus_linear on {f, g, h} against the oracle's prover on SumPolynomial[Prod[f, g], Prod[h, ones]]:
+    same round polynomials, challenges and transcript state.  default: the library's thresholds; all27: every pass above the host
+    tail through k_fold_sum27<M, PWQ> (first pass M = 0, then M = 3); off: the general four-table kernels (the form turned off)."""
+    c = zk_amd.Context(0)
+    if mode == "all27":
+        c.set_deg2_small_triple(62)
+        c.set_deg2_first_triple(0, 62)
+        c.set_deg2_triple(64, 4)
+    elif mode == "off":
+        c.set_deg2_first_triple(0, 0)
+    n = 1 << log_n
+    tabs = [O.gen_table(SEED + 520 + k, 0, n) for k in range(3)]
+    m = [MLE(t, ctx=c) for t in tabs]
+    tr, otr = zk_amd.Transcript(), O.OTranscript()
+    c.forms_used()
+    proof, pts = zk_amd.SumcheckProver.generate_proof_product_plus_linear(O.fq1(5), m[0], m[1], m[2], tr)
+    forms = c.forms_used()
+    assert ("pwq" in forms) == (mode != "off" and log_n >= 7), forms
+    if mode == "all27" and log_n >= 10:
+        assert "sum27_first" in forms and "fold_sum27" in forms and "sum9_lazy" not in forms and "sum9" not in forms, forms
+    ocoeffs, och = O.sumcheck_prove_sum([[tabs[0], tabs[1]], [tabs[2], _ones_table(n)]], O.fq1(5), otr)
+    assert np.array_equal(proof.round_polys, ocoeffs), log_n
+    assert np.array_equal(pts, och) and tr.peek_digest() == otr.peek_digest()
+    for t, src in zip(m, tabs):
+        assert np.array_equal(t.get_evaluation_points(), src)      # the factor tables are left unmodified
+
+
+@pytest.mark.parametrize("fill", ["p-1", "zero", "mixed"])
+def test_prod_plus_linear_extreme_values(fill):
+    c = zk_amd.Context(0)
+    c.set_deg2_small_triple(62)
+    c.set_deg2_first_triple(0, 62)
+    n = 1 << 11
+    pm1 = np.array([((P - 1) >> (64 * k)) & (2**64 - 1) for k in range(4)], dtype=np.uint64)
+    tabs = []
+    for k in range(3):
+        if fill == "p-1":
+            t = np.tile(pm1, (n, 1))
+        elif fill == "zero":
+            t = np.zeros((n, 4), dtype=np.uint64)
+        else:
+            t = O.gen_table(SEED + 530 + k, 0, n)
+            t[::3] = pm1
+            t[1::5] = 0
+        tabs.append(np.ascontiguousarray(t))
+    m = [MLE(t, ctx=c) for t in tabs]
+    tr, otr = zk_amd.Transcript(), O.OTranscript()
+    c.forms_used()
+    proof, pts = zk_amd.SumcheckProver.generate_proof_product_plus_linear(O.fq1(5), m[0], m[1], m[2], tr)
+    assert "pwq" in c.forms_used()
+    ocoeffs, och = O.sumcheck_prove_sum([[tabs[0], tabs[1]], [tabs[2], _ones_table(n)]], O.fq1(5), otr)
+    assert np.array_equal(proof.round_polys, ocoeffs)
+    assert np.array_equal(pts, och) and tr.peek_digest() == otr.peek_digest()
+
+
+@pytest.mark.parametrize("log_n", [7, 8, 9, 10, 12, 13, 15, 17])
+def test_sum2x2_first_pass_as_27_sums_vs_oracle(log_n):
+    """The general four-table prover with its FIRST pass as 27 sums (k_fold_sum27<0>: three rounds before the first fold)."""
+    c = zk_amd.Context(0)
+    c.set_deg2_small_triple(62)
+    c.set_deg2_first_triple(62, 21)
+    c.set_deg2_triple(64, 4)
+    n = 1 << log_n
+    tabs = [O.gen_table(SEED + 540 + k, 0, n) for k in range(4)]
+    m = [MLE(t, ctx=c) for t in tabs]
+    f = zk_amd.SumPolynomial([zk_amd.ProductPolynomial(m[:2]), zk_amd.ProductPolynomial(m[2:])])
+    tr, otr = zk_amd.Transcript(), O.OTranscript()
+    c.forms_used()
+    proof, pts = zk_amd.SumcheckProver.generate_proof_for_partial_verify(O.fq1(5), f, tr)
+    forms = c.forms_used()
+    assert "sum27_first" in forms and "pwq" not in forms and "sum9_lazy" not in forms and "sum9" not in forms, forms
+    ocoeffs, och = O.sumcheck_prove_sum([[tabs[0], tabs[1]], [tabs[2], tabs[3]]], O.fq1(5), otr)
+    assert np.array_equal(proof.round_polys, ocoeffs), log_n
     assert np.array_equal(pts, och) and tr.peek_digest() == otr.peek_digest()
 
 
@@ -753,6 +843,7 @@ def test_sum2x2_mfma_nine_sums_extreme_bytes(fill):
     c.set_deg2_mfma_sums(0)
     c.set_deg2_fused(0)
     c.set_deg2_small_triple(0)
+    c.set_deg2_first_triple(0, 0)    # first pass: the nine-sum forms this test is about
     n = 1 << 12
 
     def const_table(raw):

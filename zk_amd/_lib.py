@@ -65,6 +65,7 @@ SYMBOLS = [
     ("zk_mle_round_sums", C.c_int, [_VP, u64p]),
     ("zk_sumcheck_prove_mle", C.c_int, [_VP, _VP, C.c_int, _VP, u64p, u64p, u64p]),
     ("zk_sumcheck_prove_sum2x2", C.c_int, [_VP, C.POINTER(_VP), u64p, _VP, u64p, u64p]),
+    ("zk_sumcheck_prove_prod_plus_linear", C.c_int, [_VP, C.POINTER(_VP), u64p, _VP, u64p, u64p]),
     ("zk_sumcheck_rounds_from_block_sums", C.c_int, [_VP, u64p, C.c_int, C.c_int, u64p, u64p, u64p, u64p]),
     ("zk_shard_begin", C.c_int, [_VP, _VP, C.POINTER(_VP)]),
     ("zk_shard_end", None, [_VP]),
@@ -121,6 +122,7 @@ SYMBOLS = [
     ("zk_ctx_set_deg2_triple", C.c_int, [_VP, C.c_int, C.c_int]),
     ("zk_ctx_set_deg2_fused", C.c_int, [_VP, C.c_int]),
     ("zk_ctx_set_deg2_small_triple", C.c_int, [_VP, C.c_int]),
+    ("zk_ctx_set_deg2_first_triple", C.c_int, [_VP, C.c_int, C.c_int]),
     ("zk_ctx_set_deg2_fold3_fused", C.c_int, [_VP, C.c_int]),
     ("zk_ctx_set_validate", C.c_int, [_VP, C.c_int]),
     ("zk_mle_count_noncanonical", C.c_int, [_VP, C.POINTER(C.c_uint64)]),

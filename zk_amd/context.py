@@ -9,7 +9,7 @@ KERNELS = {"block_sums": 0, "multifold": 1, "fold": 2, "eval3": 3, "fold4_eval3"
 
 
 FORMS = ["sums_dma", "sums_reg", "wide_dma", "wide_dma_stream", "wide_reg", "wide_lds", "coop", "fold2_dma", "fold2_reg", "sum9_lazy", "sum9",
-         "fold2_sum9", "wide_mfma", "sum9_mfma", "cross64", "fold3_dma", "fold3_cross64", "fold3_cross64_mfma", "fold_sum27", "fold3_reg"]
+         "fold2_sum9", "wide_mfma", "sum9_mfma", "cross64", "fold3_dma", "fold3_cross64", "fold3_cross64_mfma", "fold_sum27", "fold3_reg", "pwq", "sum27_first"]
 
 
 class Context:
@@ -85,6 +85,11 @@ class Context:
         """Degree-2 prover: THREE rounds per pass on small tables (fold + the 27 sums of the next three rounds in one kernel) while the
         folded tables have < 2^below_log entries (0 = never)."""
         check(lib().zk_ctx_set_deg2_small_triple(self.h, below_log))
+
+    def set_deg2_first_triple(self, below_log: int = 19, linear_below_log: int = 20):
+        """Degree-2 prover: the first pass as 27 sums (three rounds) for tables of < 2^below_log entries (0 = never); linear_below_log:
+        the same for relations F G + H * 1 (the GKR phases), 0 = the GKR prover does not use its product-plus-linear kernels at all."""
+        check(lib().zk_ctx_set_deg2_first_triple(self.h, below_log, linear_below_log))
 
     def set_deg2_triple(self, from_log: int = 21, ring: int = 4):
         """Degree-2 prover: passes over tables of >= 2^from_log entries serve three rounds each (8 x 8 cross sums per term on the

@@ -1321,37 +1321,53 @@ __device__ __forceinline__ void val27_put(Val27* p, const fq& x) {
     p->h[0] = u32x4{x.v[0], x.v[1], x.v[2], x.v[3]};
     p->h[1] = u32x4{x.v[4], x.v[5], x.v[6], x.v[7]};
 }
-template <int M>
+// M = 0: no fold -- the 27 sums of the tables as they are (the first pass of a prove; `outlen` is the tables' length, D unused).
+// PWQ: the relation has the shape P W + Q * 1 (a product term plus a LINEAR term: both phases of a GKR layer, gkr.cpp): tables
+// S.t[0] = P, S.t[1] = W, S.t[2] = Q, the fourth factor is the constant one and is neither read, folded nor written (any prefix of a
+// table of ones is its own fold).  One workgroup population instead of two (gridDim.y = 1): lanes 16 .. 23 of a group fold Q's eight
+// entries beside the sixteen of P and W (lanes that idle in the general form), and a class without an oo digit adds Q's corner to its
+// product -- the constant one is 1 at 0 and 1 and 0 at oo, so the other classes get nothing from the linear term.  Half the wave
+// instructions and three quarters of the bytes of the general form for the same 27 sums.
+template <int M, bool PWQ>
 __global__ void __launch_bounds__(kThreads) k_fold_sum27(Tab4 S, Tab4w D, size_t outlen, W28<M> W, fq* __restrict__ partials) {
-    __shared__ Val27 val[kThreads / 64][2][2][27]; // [wave][octet of the wave][factor][9a + 3b + c]: 3.4 KiB per wave
+    constexpr int NV = PWQ ? 3 : 2;
+    __shared__ Val27 val[kThreads / 64][2][NV][27]; // [wave][octet of the wave][factor (2: Q)][9a + 3b + c]
     __shared__ fq red[kThreads / 64][27];
-    const int term = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int term = PWQ ? 0 : (int)blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int o2 = lane >> 5, l = lane & 31;
-    const int fac = (l >> 3) & 1, e = l & 7; // fold role (l < 16)
-    const fq* __restrict__ src = S.t[2 * term + fac];
-    fq* __restrict__ dst = D.t[2 * term + fac];
+    const int role = l >> 3, e = l & 7; // fold role: the entry e of factor 0 / 1 (role 2, PWQ: of Q)
+    const bool folds = l < 8 * NV;
+    const int ti = PWQ ? (folds ? role : 0) : 2 * term + (role & 1);
+    const fq* __restrict__ src = S.t[ti];
+    fq* __restrict__ dst = D.t[ti];
     // difference roles: step 1 (third variable, l < 8): pair (b1, b2) = l & 3 of factor l >> 2; step 2 (second variable, l < 12):
     // (b1, c) = (l % 6) / 3, l % 3 of factor l / 6; step 3 (first variable, l < 18): slot 3b + c = l % 9 of factor l / 9
     Val27* const v1 = &val[wave][o2][(l >> 2) & 1][9 * ((l >> 1) & 1) + 3 * (l & 1)];
     Val27* const v2 = &val[wave][o2][l < 6 ? 0 : 1][9 * ((l % 6) / 3) + l % 3];
     Val27* const v3 = &val[wave][o2][l < 9 ? 0 : 1][l % 9];
     const int cls = l < 27 ? l : 0;
+    const bool corner = cls / 9 != 2 && (cls / 3) % 3 != 2 && cls % 3 != 2; // no oo digit: the linear term's classes
     const size_t qn = outlen >> 3; // octet length of the folded tables
     fq acc = fq_zero();
     const size_t stride = (size_t)gridDim.x * (kThreads / 32); // octet-indices per grid step
     for (size_t j0 = (size_t)blockIdx.x * (kThreads / 32) + (size_t)wave * 2; j0 < qn; j0 += stride) { // wave-uniform
         const size_t j = j0 + o2;
         const bool live = j < qn;
-        if (l < 16) {
+        if (folds) {
             const size_t o = (size_t)e * qn + (live ? j : 0);
-            u64 a28[20];
+            fq v;
+            if constexpr (M == 0) {
+                v = fq_load(src + o);
+            } else {
+                u64 a28[20];
 #pragma unroll
-            for (int k = 0; k < 20; ++k) a28[k] = 0;
+                for (int k = 0; k < 20; ++k) a28[k] = 0;
 #pragma unroll
-            for (int b = 0; b < (1 << M); ++b) fq28_mac(a28, fq_load(src + (size_t)b * outlen + o), W.w[b]);
-            const fq v = fq28_redc(a28);
-            if (live) fq_store(dst + o, v);
-            val27_put(&val[wave][o2][fac][9 * (e >> 2) + 3 * ((e >> 1) & 1) + (e & 1)], v);
+                for (int b = 0; b < (1 << M); ++b) fq28_mac(a28, fq_load(src + (size_t)b * outlen + o), W.w[b]);
+                v = fq28_redc(a28);
+                if (live) fq_store(dst + o, v);
+            }
+            val27_put(&val[wave][o2][role][9 * (e >> 2) + 3 * ((e >> 1) & 1) + (e & 1)], v);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // wave-private table: program order, no barrier
         if (l < 8) val27_put(v1 + 2, fq_sub(val27_get(v1 + 1), val27_get(v1)));
@@ -1360,7 +1376,11 @@ __global__ void __launch_bounds__(kThreads) k_fold_sum27(Tab4 S, Tab4w D, size_t
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (l < 18) val27_put(v3 + 18, fq_sub(val27_get(v3 + 9), val27_get(v3)));
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        const fq pr = fq_mul(val27_get(&val[wave][o2][0][cls]), val27_get(&val[wave][o2][1][cls]));
+        fq pr = fq_mul(val27_get(&val[wave][o2][0][cls]), val27_get(&val[wave][o2][1][cls]));
+        if constexpr (PWQ) {
+            const fq qv = val27_get(&val[wave][o2][NV - 1][corner ? cls : 0]); // slot 0 is a corner: always written
+            if (corner) pr = fq_add(pr, qv);
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // operands in registers before the next trip overwrites the table
         if (live && l < 27) acc = fq_add(acc, pr);
     }
@@ -1611,34 +1631,44 @@ int launch_fold2_sum9(const void* const s[4], void* const d[4], size_t outlen, c
 }
 
 // launch_fold2_tables / launch_fold3_tables (m = 2 / 3) and the 27 sums of the result for the next THREE rounds in one launch (small
-// tables; outlen a multiple of 16).  Returns G > 0 when `out` holds G workgroups' shares out[g * 27 + i] for the caller to add, 0 when it
-// holds the 27 sums.
-template <int M>
+// tables; outlen a multiple of 16); m = 0: the 27 sums of the tables s as they are (outlen = their length, d unused).  pwq: the
+// relation is s[0] s[1] + s[2] * 1 (s[3], d[3] are not touched).  Returns G > 0 when `out` holds G workgroups' shares
+// out[g * 27 + i] for the caller to add, 0 when it holds the 27 sums.
+template <int M, bool PWQ>
 static int launch_fold_sum27_m(const Tab4& S, const Tab4w& D, size_t outlen, const uint32_t* w28, void* partials, void* out, hipStream_t st,
                                int host_groups_max) {
-    W28<M> W;
-    for (int b = 0; b < (1 << M); ++b)
-        for (int j = 0; j < 10; ++j) W.w[b][j] = w28[b * 10 + j];
+    W28<M> W{};
+    if (M > 0)
+        for (int b = 0; b < (1 << M); ++b)
+            for (int j = 0; j < 10; ++j) W.w[b][j] = w28[b * 10 + j];
     size_t gx = (outlen / 8 + kThreads / 32 - 1) / (kThreads / 32);
     if (gx < 1) gx = 1;
     if (gx > (size_t)kMaxBlocks9) gx = kMaxBlocks9;
     g_forms |= kFormFoldSum27;
-    if (2 * gx <= (size_t)host_groups_max) {
-        hipLaunchKernelGGL((k_fold_sum27<M>), dim3((unsigned)gx, 2), dim3(kThreads), 0, st, S, D, outlen, W, (fq*)out);
-        return (int)(2 * gx);
+    const unsigned gy = PWQ ? 1 : 2;
+    if (gy * gx <= (size_t)host_groups_max) {
+        hipLaunchKernelGGL((k_fold_sum27<M, PWQ>), dim3((unsigned)gx, gy), dim3(kThreads), 0, st, S, D, outlen, W, (fq*)out);
+        return (int)(gy * gx);
     }
-    hipLaunchKernelGGL((k_fold_sum27<M>), dim3((unsigned)gx, 2), dim3(kThreads), 0, st, S, D, outlen, W, (fq*)partials);
-    hipLaunchKernelGGL(k_reduce27, dim3(27), dim3(kThreads), 0, st, (const fq*)partials, (int)(2 * gx), (fq*)out);
+    hipLaunchKernelGGL((k_fold_sum27<M, PWQ>), dim3((unsigned)gx, gy), dim3(kThreads), 0, st, S, D, outlen, W, (fq*)partials);
+    hipLaunchKernelGGL(k_reduce27, dim3(27), dim3(kThreads), 0, st, (const fq*)partials, (int)(gy * gx), (fq*)out);
     return 0;
 }
 int launch_fold_sum27(int m, const void* const s[4], void* const d[4], size_t outlen, const uint32_t* w28, void* partials, void* out,
-                      hipStream_t st, int host_groups_max) {
-    if ((m != 2 && m != 3) || outlen < 16 || outlen % 16) return -1;
+                      hipStream_t st, int host_groups_max, bool pwq) {
+    if ((m != 0 && m != 2 && m != 3) || outlen < 16 || outlen % 16 || (m > 0 && (!w28 || !d))) return -1;
     Tab4 S;
     Tab4w D;
-    for (int k = 0; k < 4; ++k) { S.t[k] = (const fq*)s[k]; D.t[k] = (fq*)d[k]; }
-    return m == 2 ? launch_fold_sum27_m<2>(S, D, outlen, w28, partials, out, st, host_groups_max)
-                  : launch_fold_sum27_m<3>(S, D, outlen, w28, partials, out, st, host_groups_max);
+    for (int k = 0; k < 4; ++k) { S.t[k] = (const fq*)s[k]; D.t[k] = d ? (fq*)d[k] : nullptr; }
+    if (pwq) {
+        g_forms |= kFormPwq;
+        return m == 0 ? launch_fold_sum27_m<0, true>(S, D, outlen, w28, partials, out, st, host_groups_max)
+             : m == 2 ? launch_fold_sum27_m<2, true>(S, D, outlen, w28, partials, out, st, host_groups_max)
+                      : launch_fold_sum27_m<3, true>(S, D, outlen, w28, partials, out, st, host_groups_max);
+    }
+    return m == 0 ? launch_fold_sum27_m<0, false>(S, D, outlen, w28, partials, out, st, host_groups_max)
+         : m == 2 ? launch_fold_sum27_m<2, false>(S, D, outlen, w28, partials, out, st, host_groups_max)
+                  : launch_fold_sum27_m<3, false>(S, D, outlen, w28, partials, out, st, host_groups_max);
 }
 
 } // namespace zkk

@@ -317,8 +317,8 @@ static int gkr_prove_impl(zk_ctx* c, zk_circuit* ci, zk_transcript* tr, const zk
     }
     const size_t half_tab = (size_t)1 << zkk::kMaxEqVars;
     const size_t eq_half = std::min(half_tab, std::max(max_in, max_out));
-    // scratch: wt[max_out] | Eu[max_in] | A H2 ones T0 T2 T3 Wl [max_in each] | 4 eq half tables
-    const size_t n_elems = max_out + 8 * max_in + 4 * eq_half;
+    // scratch: wt[max_out] | Eu[max_in] | A H2 ones T0 T2 Wl [max_in each] | 4 eq half tables
+    const size_t n_elems = max_out + 7 * max_in + 4 * eq_half;
     if (c->gkr_scratch_cap < n_elems * kElem) { // kept in the context between proofs (a few hundred MiB at 2^20 gates per layer)
         if (c->gkr_scratch) { HIPCHK(c, hipFree(c->gkr_scratch)); c->gkr_scratch = nullptr; c->gkr_scratch_cap = 0; }
         HIPCHK(c, hipMalloc(&c->gkr_scratch, n_elems * kElem));
@@ -328,7 +328,7 @@ static int gkr_prove_impl(zk_ctx* c, zk_circuit* ci, zk_transcript* tr, const zk
     auto take = [&](size_t n) { void* p = base; base += n * kElem; return p; };
     void* wt = take(max_out);
     void* Eu = take(max_in);
-    void *A = take(max_in), *H2 = take(max_in), *ones = take(max_in), *T0 = take(max_in), *T2 = take(max_in), *T3 = take(max_in);
+    void *A = take(max_in), *H2 = take(max_in), *ones = take(max_in), *T0 = take(max_in), *T2 = take(max_in);
     void* Wl = take(max_in); // a rank's shard of the next layer's table (sharded proves)
     void* eqs[4] = {take(eq_half), take(eq_half), take(eq_half), take(eq_half)};
     zkk::launch_fill_one(ones, max_in, c->stream);
@@ -417,8 +417,10 @@ static int gkr_prove_impl(zk_ctx* c, zk_circuit* ci, zk_transcript* tr, const zk
             zkk::launch_stride_gather(Wl, Wn->d, n_loc, step, first, c->stream);
             Wt = Wl;
         }
+        // both phases have the shape t[0] t[1] + t[2] * 1 (t[3] = the table of ones): the single-GPU prover is told so
         auto prove = [&](const void* const t[4], uint64_t* co, uint64_t* chal) -> int {
-            return shard_layer ? prove_sum2x2_sharded_dev(c, t, n_loc, tr, gather_log, co, chal, fin) : prove_sum2x2_dev(c, t, n_in, tr, co, chal, fin);
+            return shard_layer ? prove_sum2x2_sharded_dev(c, t, n_loc, tr, gather_log, co, chal, fin)
+                               : prove_sum2x2_dev(c, t, n_in, tr, co, chal, fin, /*ones3=*/true);
         };
         // rounds over b
         zkk::launch_gkr_phase1(A, H2, Ly.lptr, Ly.lidx, Ly.right, Ly.op, wt, Wn->d, n_loc, step, first, c->stream);
@@ -430,10 +432,10 @@ static int gkr_prove_impl(zk_ctx* c, zk_circuit* ci, zk_transcript* tr, const zk
         const Fq wu = zkh::load(fin + 4); // W_{i+1}(u)
         // rounds over c
         build_eq(c, Eu, k_in, ch.data(), zkh::one(), eqs[0], eqs[1]);
-        zkk::launch_gkr_phase2(T0, T2, T3, Ly.rptr, Ly.ridx, Ly.left, Ly.op, wt, Eu, Wn->d, wu.l, n_loc, step, first, c->stream);
+        zkk::launch_gkr_phase2(T0, T2, Ly.rptr, Ly.ridx, Ly.left, Ly.op, wt, Eu, wu.l, n_loc, step, first, c->stream);
         HIPCHK(c, hipGetLastError());
         {
-            const void* t[4] = {T0, Wt, T2, T3};
+            const void* t[4] = {T0, Wt, T2, ones}; // P W + Q * 1 with P = wu m + ad, Q = wu ad (gkr_kernels.hip)
             if ((rc = prove(t, coeffs_out + 12 * (coeff_off + k_in), ch.data() + 4 * k_in))) return rc;
         }
         wb = wu;

@@ -30,11 +30,11 @@ void launch_fill_one(void* out, size_t n, hipStream_t st);
 //   H2[i] = sum_{add gates} wt[o] * W[right]
 void launch_gkr_phase1(void* A, void* H2, const uint32_t* lptr, const uint32_t* lidx, const uint32_t* right, const uint8_t* op,
                        const void* wt, const void* W, size_t n_loc, size_t step, size_t first, hipStream_t st);
-// phase 2 (the k_in "c" variables), b bound to u: for c = i * step + first, i < n_loc, over the gates whose RIGHT input is c:
-//   T0[i] = wu * sum_{mul gates} wt[o] * Eu[left],  T2[i] = sum_{add gates} wt[o] * Eu[left],  T3[i] = wu + W[c]
-void launch_gkr_phase2(void* T0, void* T2, void* T3, const uint32_t* rptr, const uint32_t* ridx, const uint32_t* left,
-                       const uint8_t* op, const void* wt, const void* Eu, const void* W, const uint64_t wu[4], size_t n_loc, size_t step,
-                       size_t first, hipStream_t st);
+// phase 2 (the k_in "c" variables), b bound to u: for c = i * step + first, i < n_loc, over the gates whose RIGHT input is c, with
+// m = sum_{mul gates} wt[o] * Eu[left] and ad = sum_{add gates} wt[o] * Eu[left]:
+//   P[i] = wu * m + ad,  Q[i] = wu * ad     (the relation m wu W(c) + ad (wu + W(c)) written as P W + Q * 1)
+void launch_gkr_phase2(void* P, void* Q, const uint32_t* rptr, const uint32_t* ridx, const uint32_t* left, const uint8_t* op,
+                       const void* wt, const void* Eu, const uint64_t wu[4], size_t n_loc, size_t step, size_t first, hipStream_t st);
 // out[i] = in[i * step + first], i < n_loc
 void launch_stride_gather(void* out, const void* in, size_t n_loc, size_t step, size_t first, hipStream_t st);
 // verifier: per-block shares (2 per block: add, mul) of sum_g wt[o_g] eq(u,l_g) eq(v,r_g); returns the block count (<= 1024)

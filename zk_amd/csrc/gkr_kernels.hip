@@ -116,10 +116,13 @@ __global__ void __launch_bounds__(kT) k_gkr_phase1(fq* __restrict__ A, fq* __res
     }
 }
 
-__global__ void __launch_bounds__(kT) k_gkr_phase2(fq* __restrict__ T0, fq* __restrict__ T2, fq* __restrict__ T3,
+// With m(c), ad(c) the mul and add predicates at (rho, u, c) the layer relation over c is  m(c) wu W(c) + ad(c) (wu + W(c))
+// (wu = W(u)); as polynomials in c that is  P(c) W(c) + Q(c) * 1  with  P = wu m + ad,  Q = wu ad  -- the same round polynomials in
+// exact arithmetic, from three tables and a constant instead of four tables (phase 1 has that shape already: A W + H2 * 1).
+__global__ void __launch_bounds__(kT) k_gkr_phase2(fq* __restrict__ P, fq* __restrict__ Q,
                                                    const u32* __restrict__ rptr, const u32* __restrict__ ridx,
                                                    const u32* __restrict__ left, const uint8_t* __restrict__ op,
-                                                   const fq* __restrict__ wt, const fq* __restrict__ Eu, const fq* __restrict__ W, fq wu,
+                                                   const fq* __restrict__ wt, const fq* __restrict__ Eu, fq wu,
                                                    size_t n_loc, size_t step, size_t first) {
     const size_t stride = (size_t)gridDim.x * kT;
     for (size_t i = (size_t)blockIdx.x * kT + threadIdx.x; i < n_loc; i += stride) {
@@ -131,9 +134,8 @@ __global__ void __launch_bounds__(kT) k_gkr_phase2(fq* __restrict__ T0, fq* __re
             if (op[g]) m = fq_add(m, t);
             else ad = fq_add(ad, t);
         }
-        fq_store(T0 + i, fq_mul(m, wu));
-        fq_store(T2 + i, ad);
-        fq_store(T3 + i, fq_add(wu, fq_load(W + c)));
+        fq_store(P + i, fq_add(fq_mul(m, wu), ad));
+        fq_store(Q + i, fq_mul(ad, wu));
     }
 }
 
@@ -232,11 +234,10 @@ void launch_gkr_phase1(void* A, void* H2, const uint32_t* lptr, const uint32_t* 
     hipLaunchKernelGGL(k_gkr_phase1, dim3(grid1d(n_loc)), dim3(kT), 0, st, (fq*)A, (fq*)H2, lptr, lidx, right, op, (const fq*)wt, (const fq*)W,
                        n_loc, step, first);
 }
-void launch_gkr_phase2(void* T0, void* T2, void* T3, const uint32_t* rptr, const uint32_t* ridx, const uint32_t* left, const uint8_t* op,
-                       const void* wt, const void* Eu, const void* W, const uint64_t wu[4], size_t n_loc, size_t step, size_t first,
-                       hipStream_t st) {
-    hipLaunchKernelGGL(k_gkr_phase2, dim3(grid1d(n_loc)), dim3(kT), 0, st, (fq*)T0, (fq*)T2, (fq*)T3, rptr, ridx, left, op, (const fq*)wt,
-                       (const fq*)Eu, (const fq*)W, to_fq4(wu), n_loc, step, first);
+void launch_gkr_phase2(void* P, void* Q, const uint32_t* rptr, const uint32_t* ridx, const uint32_t* left, const uint8_t* op,
+                       const void* wt, const void* Eu, const uint64_t wu[4], size_t n_loc, size_t step, size_t first, hipStream_t st) {
+    hipLaunchKernelGGL(k_gkr_phase2, dim3(grid1d(n_loc)), dim3(kT), 0, st, (fq*)P, (fq*)Q, rptr, ridx, left, op, (const fq*)wt,
+                       (const fq*)Eu, to_fq4(wu), n_loc, step, first);
 }
 void launch_stride_gather(void* out, const void* in, size_t n_loc, size_t step, size_t first, hipStream_t st) {
     hipLaunchKernelGGL(k_stride_gather, dim3(grid1d(n_loc)), dim3(kT), 0, st, (fq*)out, (const fq*)in, n_loc, step, first);

@@ -40,6 +40,8 @@ enum Form : unsigned {
     kFormFold3Cross64Mfma = 1u << 17, // k_fold3_cross64_mfma (the same sweep with the fold on the matrix cores)
     kFormFoldSum27 = 1u << 18,    // k_fold_sum27 (small tables: fold + the 27 sums of the next three rounds)
     kFormFold3Reg = 1u << 19,     // k_fold3_tables (small tables: the three-variable fold of all four tables in one launch)
+    kFormPwq = 1u << 20,          // k_fold_sum27<M, PWQ = true>: the product-plus-linear-term form of the GKR phases (the constant-one factor is never read)
+    kFormSum27First = 1u << 21,   // k_fold_sum27<0, .>: the first pass of a prove as 27 sums (three rounds) instead of nine
 };
 extern thread_local unsigned g_forms;
 // Size thresholds of the LDS-DMA forms (log2 of entries; defaults = the measured break-even points)
@@ -53,6 +55,10 @@ struct DmaGates {
     int wide_mfma_depth = 2;       // its pipeline depth K (2..4): table rows of K steps in flight per wave
     int deg2_triple_from_log = 21; // degree-2 prover: three rounds per pass (k_cross64_mfma + m = 3 fold) on tables of >= 2^k entries; 64 = never
     int deg2_fused_below_log = 20; // degree-2 prover: fold + nine sums in one kernel (k_fold2_sum9) for folded tables below 2^k entries; 0 = never
+    int deg2_sum27_first_below_log = 19; // degree-2 prover: the FIRST pass as 27 sums (k_fold_sum27<0>: three rounds before the first fold) for tables below
+                                         // 2^k entries; 0 = never (measured: 4 x 2^18 prove 0.224 -> 0.199 ms, 2^14 0.129 -> 0.122; at 2^20 the nine-sum pass wins)
+    int deg2_pwq_first_below_log = 20;   // the same threshold for relations F G + H * 1 (ones3: the GKR phases), whose 27-sum passes run in the
+                                         // product-plus-linear form; 0 = that form off (GKR config 5 layers: 11.35 ms off, 10.17 with 20, 10.65 with 21)
     int deg2_sum27_below_log = 20; // degree-2 prover: THREE rounds per pass on small tables too (k_fold_sum27) while the folded tables have fewer
                                    // than 2^k entries; 0 = never (measured: 4 x 2^16 .. 2^24 proves 4-14 % faster with 20, 21 slower at 2^23)
     int deg2_fold3_fused = 8;      // three-round passes: fold fused with the next level's cross sums; 8 = the fold on the matrix cores too
@@ -121,7 +127,7 @@ int launch_fold2_sum9(const void* const s[4], void* const d[4], size_t outlen, c
 // the next THREE rounds (k_fold_sum27: small tables, outlen a multiple of 16).  Returns like launch_fold2_sum9 with 27 elements per
 // workgroup (G > 0: out[g * 27 + i] = workgroup g's share), 0 when out holds the 27 sums, < 0 for a shape it does not take.
 int launch_fold_sum27(int m, const void* const s[4], void* const d[4], size_t outlen, const uint32_t* w28, void* partials, void* out,
-                      hipStream_t st, int host_groups_max = 0);
+                      hipStream_t st, int host_groups_max, bool pwq);
 // launch_fold3_tables followed by launch_cross64 on d[], in one sweep: the folded tables are not re-read (needs cross64_fits(outlen / 8));
 // ring = LDS-DMA slots per wave (3, 4 or 5)
 void launch_fold3_cross64(const void* const s[4], void* const d[4], size_t outlen, const uint64_t* r3, const uint64_t two24[4], void* wbuf,

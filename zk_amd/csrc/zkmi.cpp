@@ -5,6 +5,7 @@
 // fold_k fused with reduce_{k+1}.  The table never leaves HBM; per round (d+1) x 32 B come
 // back to the host and 32 B (the challenge) go out as a kernel argument.
 #include "zkmi_internal.hpp"
+#include "gkr_kernels.h" // launch_fill_one
 
 extern "C" {
 
@@ -922,8 +923,11 @@ void zki::host_rounds_from_cross64(zk_transcript* tr, const uint64_t* cross, int
 }
 
 // two (nine sums) or three (8 x 8 cross sums) rounds per device pass
+// ones3: tables[3] is a table of ones (the relation is tables[0] tables[1] + tables[2] * 1: both phases of a GKR layer); the 27-sum
+// passes then run in their product-plus-linear form, which neither reads nor folds it (cur[3] stays the caller's table: a prefix of
+// a table of ones is its own fold), every other kernel treats it as the ordinary table it also is
 static int prove_sum2x2_pairs(zk_ctx* c, const void* const tables[4], size_t len, zk_transcript* tr, uint64_t* coeffs_out,
-                              uint64_t* challenges_out, uint64_t* final_out) {
+                              uint64_t* challenges_out, uint64_t* final_out, bool ones3) {
     int rc = set_device(c);
     if (rc) return rc;
     const void* cur[4];
@@ -973,8 +977,22 @@ static int prove_sum2x2_pairs(zk_ctx* c, const void* const tables[4], size_t len
             for (int i = 0; i < 9; ++i) S[i] = zkh::load(c->sums_host + 4 * i);
         }
     };
+    const bool pwq = ones3 && c->gates.deg2_pwq_first_below_log > 0;
     int K = 0;
-    if (curlen > kHostTail) K = launch_sums(cur, curlen);
+    if (curlen > kHostTail) {
+        const int fb0 = pwq ? c->gates.deg2_pwq_first_below_log : c->gates.deg2_sum27_first_below_log;
+        if (fb0 > 0 && curlen < ((size_t)1 << std::min(fb0, 62)) && curlen % 16 == 0 && !deg2_triple_ok(c, curlen)) {
+            // the first pass as 27 sums: three rounds before the first fold
+            ProfScope ps(c, ZK_K_SUM9, (uint64_t)curlen * 32 * (pwq ? 3 : 4));
+            sums_kind = zkk::launch_fold_sum27(0, cur, nullptr, curlen, nullptr, c->partials, c->sums_host_dev, c->stream, kHostSumGroups, pwq);
+            if (sums_kind < 0) return ZK_E_ARG;
+            zkk::g_forms |= zkk::kFormSum27First;
+            have27 = true;
+            K = 3;
+        } else {
+            K = launch_sums(cur, curlen);
+        }
+    }
     while (curlen > kHostTail) {
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1006,11 +1024,12 @@ static int prove_sum2x2_pairs(zk_ctx* c, const void* const tables[4], size_t len
         const int fb = c->gates.deg2_fused_below_log, tb = c->gates.deg2_sum27_below_log;
         if (tb > 0 && outlen > kHostTail && outlen < ((size_t)1 << std::min(tb, 62)) && !deg2_triple_ok(c, outlen)) {
             // small tables: the fold of this pass's K variables and the 27 sums that serve the next THREE rounds in one launch
-            ProfScope ps(c, ZK_K_FOLD2X4_SUM9, (uint64_t)curlen * 32 * 4 + (uint64_t)outlen * 32 * 4);
+            ProfScope ps(c, ZK_K_FOLD2X4_SUM9, ((uint64_t)curlen * 32 + (uint64_t)outlen * 32) * (pwq ? 3 : 4));
             uint32_t w28[8 * 10];
             eq_weights28(rs, (unsigned)K, w28);
-            sums_kind = zkk::launch_fold_sum27(K, cur, dst, outlen, w28, c->partials, c->sums_host_dev, c->stream, kHostSumGroups);
+            sums_kind = zkk::launch_fold_sum27(K, cur, dst, outlen, w28, c->partials, c->sums_host_dev, c->stream, kHostSumGroups, pwq);
             if (sums_kind < 0) return ZK_E_ARG;
+            if (pwq) dst[3] = const_cast<void*>(cur[3]); // not folded: still the table of ones
             have27 = true;
             K = 3;
         } else if (K == 3 && c->gates.deg2_fold3_fused && deg2_triple_ok(c, outlen)) {
@@ -1058,9 +1077,9 @@ static int prove_sum2x2_pairs(zk_ctx* c, const void* const tables[4], size_t len
 }
 
 int zki::prove_sum2x2_dev(zk_ctx* c, const void* const tables[4], size_t len, zk_transcript* tr, uint64_t* coeffs_out,
-                          uint64_t* challenges_out, uint64_t* final_out) {
+                          uint64_t* challenges_out, uint64_t* final_out, bool ones3) {
     if (len >= 2 && !coeffs_out) return ZK_E_ARG;
-    if (c->deg2_pairs && len >= 4) return prove_sum2x2_pairs(c, tables, len, tr, coeffs_out, challenges_out, final_out);
+    if (c->deg2_pairs && len >= 4) return prove_sum2x2_pairs(c, tables, len, tr, coeffs_out, challenges_out, final_out, ones3);
     return prove_sum2x2_single(c, tables, len, tr, coeffs_out, challenges_out, final_out);
 }
 
@@ -1076,6 +1095,26 @@ int zk_sumcheck_prove_sum2x2(zk_ctx* c, zk_mle* const tables[4], const uint64_t 
         if (tables[k]->len != len) return ZK_E_LEN_MISMATCH; // product_polynomial.rs:15-19, sum_polynomial.rs:15-19
     const void* t[4] = {tables[0]->d, tables[1]->d, tables[2]->d, tables[3]->d};
     return prove_sum2x2_dev(c, t, len, tr, coeffs_out, challenges_out, nullptr);
+}
+
+int zk_sumcheck_prove_prod_plus_linear(zk_ctx* c, zk_mle* const tables[3], const uint64_t claim[4], zk_transcript* tr,
+                                       uint64_t* coeffs_out, uint64_t* challenges_out) {
+    if (!c || !tables || !claim || !tr) return ZK_E_ARG;
+    for (int k = 0; k < 3; ++k)
+        if (!tables[k] || tables[k]->ctx != c) return ZK_E_ARG;
+    const size_t len = tables[0]->len;
+    for (int k = 1; k < 3; ++k)
+        if (tables[k]->len != len) return ZK_E_LEN_MISMATCH; // product_polynomial.rs:15-19, sum_polynomial.rs:15-19
+    int rc = set_device(c);
+    if (rc) return rc;
+    void* ones = nullptr;
+    HIPCHK(c, hipMalloc(&ones, len * kElem));
+    zkk::launch_fill_one(ones, len, c->stream);
+    const void* t[4] = {tables[0]->d, tables[1]->d, tables[2]->d, ones};
+    rc = prove_sum2x2_dev(c, t, len, tr, coeffs_out, challenges_out, nullptr, /*ones3=*/true);
+    (void)hipStreamSynchronize(c->stream); // no kernel reads `ones` after this
+    (void)hipFree(ones);
+    return rc;
 }
 
 // ---- degree-2 prover in steps (sharded tables) ---------------------------------------------------
@@ -1376,6 +1415,12 @@ int zk_ctx_set_deg2_mfma_sums(zk_ctx* c, int from_log) {
 int zk_ctx_set_deg2_small_triple(zk_ctx* c, int below_log) {
     if (!c || below_log < 0 || below_log > 62) return ZK_E_ARG;
     c->gates.deg2_sum27_below_log = below_log;
+    return ZK_OK;
+}
+int zk_ctx_set_deg2_first_triple(zk_ctx* c, int below_log, int linear_below_log) {
+    if (!c || below_log < 0 || below_log > 62 || linear_below_log < 0 || linear_below_log > 62) return ZK_E_ARG;
+    c->gates.deg2_sum27_first_below_log = below_log;
+    c->gates.deg2_pwq_first_below_log = linear_below_log;
     return ZK_OK;
 }
 int zk_ctx_set_deg2_fused(zk_ctx* c, int below_log) {

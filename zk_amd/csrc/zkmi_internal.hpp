@@ -310,7 +310,7 @@ int fold_pass(const zk_ctx& k, const uint64_t two24[4], const void* src, void* d
 int prove_mle_dev(zk_ctx* c, const void* table, unsigned n, zk_transcript* tr, uint64_t claim_out[4], uint64_t* coeffs_out,
                   uint64_t* challenges_out);
 int prove_sum2x2_dev(zk_ctx* c, const void* const tables[4], size_t len, zk_transcript* tr, uint64_t* coeffs_out,
-                     uint64_t* challenges_out, uint64_t* final_out);
+                     uint64_t* challenges_out, uint64_t* final_out, bool ones3 = false);
 // the host part of three rounds from the ranks' shares of the 2 x 64 cross sums (zkmi.cpp)
 void host_rounds_from_cross64(zk_transcript* tr, const uint64_t* cross, int world, uint64_t* coeffs_out, uint64_t* rs);
 // defined in sharded.cpp: the same for tables sharded over the ranks of the context's communicator (len_local entries per rank)

@@ -75,6 +75,22 @@ class SumcheckProver:
         return SumCheckProof(claim.copy(), coeffs[:n]), ch[:n]
 
 
+    @staticmethod
+    def generate_proof_product_plus_linear(initial_claim_sum, f: MultiLinearPolynomial, g: MultiLinearPolynomial, h: MultiLinearPolynomial,
+                                           transcript: Transcript):
+        """generate_proof_for_partial_verify (prover.rs:175-190) for SumPolynomial[Product[f, g], Product[h, ones]] -- the relation
+        f g + h of a GKR phase -- without the table of ones: same proof bytes, the constant factor is never read."""
+        ctx = f.ctx
+        n = f.number_of_variables()
+        coeffs = np.empty((max(n, 1), 3, 4), dtype=np.uint64)
+        ch = np.empty((max(n, 1), 4), dtype=np.uint64)
+        claim = np.ascontiguousarray(initial_claim_sum, dtype=np.uint64)
+        arr = (C.c_void_p * 3)(f.h, g.h, h.h)
+        check(lib().zk_sumcheck_prove_prod_plus_linear(ctx.h, arr, claim.ctypes.data_as(u64p), transcript.h,
+                                                       coeffs.ctypes.data_as(u64p), ch.ctypes.data_as(u64p)), ctx.h)
+        return SumCheckProof(claim.copy(), coeffs[:n]), ch[:n]
+
+
 class SumcheckVerifier:
     @staticmethod
     def partial_verify(proof: SumCheckProof, transcript: Transcript):
