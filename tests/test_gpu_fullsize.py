@@ -134,8 +134,10 @@ def test_sum2x2_2pow26_config4_size():
     ctx.forms_used()
     proof1, pts1 = zk_amd.SumcheckProver.generate_proof_for_partial_verify(O.fq1(0), f, zk_amd.Transcript())
     assert "cross64" not in ctx.forms_used()
-    ctx.set_deg2_triple(21, 4)
+    ctx.set_deg2_triple(21, 4)          # back to the library defaults: the context is shared with later tests
     ctx.set_deg2_fused(20)
+    ctx.set_deg2_small_triple(20)
+    ctx.set_deg2_first_triple(19, 20)
     assert np.array_equal(proof1.round_polys, proof0.round_polys) and np.array_equal(pts1, pts)
 
 

@@ -1022,7 +1022,8 @@ static int prove_sum2x2_pairs(zk_ctx* c, const void* const tables[4], size_t len
         void* dst[4];
         for (int t = 0; t < 4; ++t) dst[t] = (uint8_t*)c->work[pass & 1] + (size_t)t * outlen * kElem;
         const int fb = c->gates.deg2_fused_below_log, tb = c->gates.deg2_sum27_below_log;
-        if (tb > 0 && outlen > kHostTail && outlen < ((size_t)1 << std::min(tb, 62)) && !deg2_triple_ok(c, outlen)) {
+        const bool cont3 = K == 3 && !have27 && c->gates.deg2_fold3_fused && deg2_triple_cont_ok(c, outlen); // this fold leaves the next cross sums
+        if (tb > 0 && outlen > kHostTail && outlen < ((size_t)1 << std::min(tb, 62)) && !deg2_triple_ok(c, outlen) && !cont3) {
             // small tables: the fold of this pass's K variables and the 27 sums that serve the next THREE rounds in one launch
             ProfScope ps(c, ZK_K_FOLD2X4_SUM9, ((uint64_t)curlen * 32 + (uint64_t)outlen * 32) * (pwq ? 3 : 4));
             uint32_t w28[8 * 10];
@@ -1032,7 +1033,7 @@ static int prove_sum2x2_pairs(zk_ctx* c, const void* const tables[4], size_t len
             if (pwq) dst[3] = const_cast<void*>(cur[3]); // not folded: still the table of ones
             have27 = true;
             K = 3;
-        } else if (K == 3 && c->gates.deg2_fold3_fused && deg2_triple_ok(c, outlen)) {
+        } else if (cont3) {
             // the next pass serves three rounds too: its cross sums come out of this fold's sweep
             ProfScope ps(c, ZK_K_FOLD2X4_SUM9, (uint64_t)curlen * 32 * 4 + (uint64_t)outlen * 32 * 4);
             zkk::launch_fold3_cross64(cur, dst, outlen, rs, c->two24, c->wide_w, c->gates.deg2_fold3_fused, c->partials, c->sums_host_dev, c->stream,

@@ -158,6 +158,12 @@ inline bool deg2_triple_ok(const zk_ctx* c, size_t n) {
     const int tf = c->gates.deg2_triple_from_log;
     return tf < 63 && n >= 512 && n >= ((size_t)1 << std::max(tf, 0)) && zkk::cross64_fits(n / 8);
 }
+// ... and does the fold that FOLLOWS a three-round pass leave its result's cross sums too (k_fold3_cross64*)?  One size class further
+// down than a first pass: the sweep is already running in that form, and the alternative is four fold launches plus a nine-sum pass
+inline bool deg2_triple_cont_ok(const zk_ctx* c, size_t n) {
+    const int tf = c->gates.deg2_triple_from_log;
+    return tf < 63 && n >= 512 && n >= ((size_t)1 << std::max(tf - 1, 0)) && zkk::cross64_fits(n / 8);
+}
 
 inline int ensure_work(zk_ctx* c, int which, size_t bytes) {
     if (c->work_cap[which] >= bytes) return ZK_OK;
