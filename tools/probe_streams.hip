@@ -45,6 +45,75 @@ __global__ void __launch_bounds__(256) k_runs(const u32x4* __restrict__ src, u32
     }
     if (acc[0] == 0x12345 && acc[1] == 77) dst[threadIdx.x] = acc;
 }
+// the wide fold's pattern: NR rows of `row16` units each at a stride of row16 (the table seen as NR x row16), a wave has U consecutive
+// rows of one 1 KiB tile in flight (tile j = the same offset in every row); rot16: row b rotated by (b % U) * rot16 units inside its row
+template <int U>
+__global__ void __launch_bounds__(256) k_rows(const u32x4* __restrict__ src, u32x4* __restrict__ dst, size_t row16, int nrows, size_t rot16) {
+    u32x4 acc = {0, 0, 0, 0};
+    const int lane = threadIdx.x & 63;
+    const size_t waves = (size_t)gridDim.x * 4, wave = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    for (size_t j = wave * 64; j < row16; j += waves * 64) {
+        for (int b0 = 0; b0 < nrows; b0 += U) {
+            u32x4 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) v[u] = __builtin_nontemporal_load(src + (size_t)(b0 + u) * row16 + ((j + lane + (size_t)u * rot16) & (row16 - 1)));
+#pragma unroll
+            for (int u = 0; u < U; ++u) acc ^= v[u];
+        }
+    }
+    if (acc[0] == 0x12345 && acc[1] == 77) dst[threadIdx.x] = acc;
+}
+// what an interleaved schedule of the wide fold would have in flight: U rows (same offset: aliased) of each of G tiles 4 KiB apart;
+// a wave owns the G tiles j + 4 KiB * k and walks the rows U at a time
+template <int U, int G>
+__global__ void __launch_bounds__(256) k_rows_tiles(const u32x4* __restrict__ src, u32x4* __restrict__ dst, size_t row16, int nrows) {
+    u32x4 acc = {0, 0, 0, 0};
+    const int lane = threadIdx.x & 63;
+    const size_t waves = (size_t)gridDim.x * 4, wave = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    // windows of 2 G KiB-tiles... a wave pair shares a window of 2 G tiles of 2 KiB: wave parity picks the odd or even 2 KiB halves
+    for (size_t win = wave >> 1; win * (size_t)(G * 256) < row16; win += waves >> 1) {
+        const size_t j = win * (size_t)(G * 256) + (wave & 1) * 128; // units of 16 B: a window is G x 4 KiB, this wave's half of each 4 KiB
+        for (int b0 = 0; b0 < nrows; b0 += U) {
+            u32x4 v[U][G][2];
+#pragma unroll
+            for (int k = 0; k < G; ++k)
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) v[u][k][h] = __builtin_nontemporal_load(src + (size_t)(b0 + u) * row16 + j + (size_t)k * 256 + h * 64 + lane);
+#pragma unroll
+            for (int k = 0; k < G; ++k)
+#pragma unroll
+                for (int u = 0; u < U; ++u) acc ^= v[u][k][0] ^ v[u][k][1];
+        }
+    }
+    if (acc[0] == 0x12345 && acc[1] == 77) dst[threadIdx.x] = acc;
+}
+// register loads in the operand layout of the matrix-core wide fold: per step a wave reads rows 2 bp, 2 bp + 1 of its group (64
+// outputs = 2 KiB per row) as four 16-byte loads per lane -- lane (g, n), tile nt: row 2 bp + (g >> 1), output 16 nt + n, half g & 1,
+// i.e. each instruction covers 2 rows x 512 contiguous bytes; S steps in flight
+template <int S>
+__global__ void __launch_bounds__(256) k_rows_mfma(const u32x4* __restrict__ src, u32x4* __restrict__ dst, size_t row16, int nrows) {
+    u32x4 acc = {0, 0, 0, 0};
+    const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15;
+    const size_t waves = (size_t)gridDim.x * 4, wave = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const size_t ngroups = row16 / 128; // 128 units = 2 KiB
+    for (size_t grp = wave; grp < ngroups; grp += waves) {
+        const u32x4* base = src + (size_t)(g >> 1) * row16 + grp * 128 + (size_t)n * 2 + (g & 1);
+        for (int bp0 = 0; bp0 < nrows / 2; bp0 += S) {
+            u32x4 v[S][4];
+#pragma unroll
+            for (int q = 0; q < S; ++q)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) v[q][nt] = __builtin_nontemporal_load(base + (size_t)(2 * (bp0 + q)) * row16 + nt * 32);
+#pragma unroll
+            for (int q = 0; q < S; ++q)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) acc ^= v[q][nt];
+        }
+    }
+    if (acc[0] == 0x12345 && acc[1] == 77) dst[threadIdx.x] = acc;
+}
 __global__ void __launch_bounds__(256) k_write(u32x4* __restrict__ dst, size_t n16) {
     const size_t stride = (size_t)gridDim.x * 256;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += stride) dst[i] = u32x4{1, 2, 3, (unsigned)i};
@@ -93,6 +162,30 @@ int main() {
         timeit("1 stream, runs of 8 KiB per wave", [&] { hipLaunchKernelGGL((k_runs<1, 8>), dim3(grid), dim3(256), 0, 0, src, dst, src16); });
         timeit("32 streams, same offset", [&] { hipLaunchKernelGGL(k_streams<32>, dim3(grid), dim3(256), 0, 0, src, dst, src16 / 32, (size_t)0); });
         timeit("32 streams, stream r rotated by r x 4352 B", [&] { hipLaunchKernelGGL(k_streams<32>, dim3(grid), dim3(256), 0, 0, src, dst, src16 / 32, (size_t)4352 / 16); });
+    }
+    // the wide fold 2^28 -> 2^20: 256 rows of 32 MiB; the degree-2 folds: 8 rows of 1 GiB
+    for (int grid : {256, 512, 1024, 2048}) {
+        printf("--- rows of one tile in flight per wave, grid %d x 256 ---\n", grid);
+        const size_t r256 = src16 / 256, r8 = src16 / 8;
+        timeit("256 rows x 32 MiB, 4 rows in flight", [&] { hipLaunchKernelGGL(k_rows<4>, dim3(grid), dim3(256), 0, 0, src, dst, r256, 256, (size_t)0); });
+        timeit("256 rows x 32 MiB, 4 rows in flight, rotated by 4 KiB", [&] { hipLaunchKernelGGL(k_rows<4>, dim3(grid), dim3(256), 0, 0, src, dst, r256, 256, (size_t)256); });
+        timeit("256 rows x 32 MiB, 8 rows in flight", [&] { hipLaunchKernelGGL(k_rows<8>, dim3(grid), dim3(256), 0, 0, src, dst, r256, 256, (size_t)0); });
+        timeit("256 rows x 32 MiB, 8 rows in flight, rotated by 4 KiB", [&] { hipLaunchKernelGGL(k_rows<8>, dim3(grid), dim3(256), 0, 0, src, dst, r256, 256, (size_t)256); });
+        timeit("256 rows x 32 MiB, 16 rows in flight", [&] { hipLaunchKernelGGL(k_rows<16>, dim3(grid), dim3(256), 0, 0, src, dst, r256, 256, (size_t)0); });
+        timeit("256 rows x 32 MiB, 16 rows in flight, rotated by 4 KiB", [&] { hipLaunchKernelGGL(k_rows<16>, dim3(grid), dim3(256), 0, 0, src, dst, r256, 256, (size_t)256); });
+        timeit("256 rows x 32 MiB, 2 KiB x 2 rows x 1 tile in flight", [&] { hipLaunchKernelGGL((k_rows_tiles<2, 1>), dim3(grid), dim3(256), 0, 0, src, dst, r256, 256); });
+        timeit("256 rows x 32 MiB, 2 KiB x 4 rows x 1 tile in flight", [&] { hipLaunchKernelGGL((k_rows_tiles<4, 1>), dim3(grid), dim3(256), 0, 0, src, dst, r256, 256); });
+        timeit("256 rows x 32 MiB, 2 KiB x 2 rows x 2 tiles (4 KiB apart) in flight", [&] { hipLaunchKernelGGL((k_rows_tiles<2, 2>), dim3(grid), dim3(256), 0, 0, src, dst, r256, 256); });
+        timeit("256 rows x 32 MiB, 2 KiB x 2 rows x 4 tiles (4 KiB apart) in flight", [&] { hipLaunchKernelGGL((k_rows_tiles<2, 4>), dim3(grid), dim3(256), 0, 0, src, dst, r256, 256); });
+        timeit("256 rows x 32 MiB, 2 KiB x 1 row x 4 tiles (4 KiB apart) in flight", [&] { hipLaunchKernelGGL((k_rows_tiles<1, 4>), dim3(grid), dim3(256), 0, 0, src, dst, r256, 256); });
+        timeit("256 rows x 32 MiB, 2 KiB x 2 rows x 8 tiles (4 KiB apart) in flight", [&] { hipLaunchKernelGGL((k_rows_tiles<2, 8>), dim3(grid), dim3(256), 0, 0, src, dst, r256, 256); });
+        timeit("256 rows x 32 MiB, matrix-operand layout, 2 steps (8 KiB) in flight", [&] { hipLaunchKernelGGL(k_rows_mfma<2>, dim3(grid), dim3(256), 0, 0, src, dst, r256, 256); });
+        timeit("256 rows x 32 MiB, matrix-operand layout, 4 steps (16 KiB) in flight", [&] { hipLaunchKernelGGL(k_rows_mfma<4>, dim3(grid), dim3(256), 0, 0, src, dst, r256, 256); });
+        timeit("256 rows x 32 MiB, matrix-operand layout, 8 steps (32 KiB) in flight", [&] { hipLaunchKernelGGL(k_rows_mfma<8>, dim3(grid), dim3(256), 0, 0, src, dst, r256, 256); });
+        timeit("8 rows x 1 GiB, 8 rows in flight", [&] { hipLaunchKernelGGL(k_rows<8>, dim3(grid), dim3(256), 0, 0, src, dst, r8, 8, (size_t)0); });
+        timeit("8 rows x 1 GiB, 8 rows in flight, rotated by 4 KiB", [&] { hipLaunchKernelGGL(k_rows<8>, dim3(grid), dim3(256), 0, 0, src, dst, r8, 8, (size_t)256); });
+        timeit("8 rows x 1 GiB, 2 rows in flight", [&] { hipLaunchKernelGGL(k_rows<2>, dim3(grid), dim3(256), 0, 0, src, dst, r8, 8, (size_t)0); });
+        timeit("8 rows x 1 GiB, 2 rows in flight, rotated by 4 KiB", [&] { hipLaunchKernelGGL(k_rows<2>, dim3(grid), dim3(256), 0, 0, src, dst, r8, 8, (size_t)256); });
     }
     CHK(hipGetLastError());
     CHK(hipDeviceSynchronize());

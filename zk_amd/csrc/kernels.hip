@@ -372,7 +372,7 @@ __global__ void __launch_bounds__(kThreads) k_eq_weights_mfma(ChalWide ch, int m
 template <bool BIG, int K>
 __global__ void __launch_bounds__(kThreads) k_multifold_wide_mfma(const fq* __restrict__ src, fq* __restrict__ dst, size_t Lout,
                                                                    const u32x4* __restrict__ tiles, int m, int log_ob, fq kfix,
-                                                                   fq* __restrict__ partials) {
+                                                                   fq* __restrict__ partials, int spread) {
     constexpr int NP = K + 2, NW = K + 1; // step j issues W(j + K), R(j + K + 1)
     __shared__ u32x4 ring[kThreads / 64][NP][2][128]; // per wave: NP steps x 2 table rows x 2 KiB
     __shared__ u32x4 wring[NW][4][64];                // per workgroup: NW steps x 4 column tiles x 1 KiB
@@ -384,8 +384,12 @@ __global__ void __launch_bounds__(kThreads) k_multifold_wide_mfma(const fq* __re
     const size_t Lb = Lout >> log_ob, j0 = (size_t)c * Lb;
     const unsigned ngroups = (unsigned)(Lb >> 6), gstride = gpb * (kThreads / 64);
     const unsigned nbp = 1u << (m - 1);
-    const unsigned first = wi * (kThreads / 64); // the workgroup's first group: wave 0's, which has the most
-    const unsigned g0 = first + wave;
+    // Which groups (64 outputs = 2 KiB of every row) a workgroup's four waves take.  Packed: four consecutive groups, 8 KiB of each
+    // row -- every load the workgroup has in flight (rows 2 bp .. of ONE 8 KiB window, the rows 32 MiB apart) then falls on the same
+    // two of the eight memory stacks (address bits 12-14; tools/probe_streams.hip: 6.4 TB/s for that pattern, 6.9-7.1 spread out).
+    // Spread: groups 4 KiB x 2 apart (wave w: first + 4 w inside a window of 16 groups that four workgroups share), four stacks.
+    const unsigned first = spread ? (wi >> 2) * 16 + (wi & 3) : wi * (kThreads / 64); // wave 0's group: the smallest, so it has the most steps
+    const unsigned g0 = first + (spread ? 4 * wave : wave);
     const unsigned mysteps = (g0 < ngroups ? (ngroups - g0 + gstride - 1) / gstride : 0) * nbp;
     const unsigned wgsteps = (first < ngroups ? (ngroups - first + gstride - 1) / gstride : 0) * nbp;
 
@@ -504,6 +508,131 @@ __global__ void __launch_bounds__(kThreads) k_multifold_wide_mfma(const fq* __re
     const fq wsum = fq_wave_sum(run);
     __syncthreads();
     fq* red = reinterpret_cast<fq*>(&wring[0][0][0]);
+    if (lane == 0) red[wave] = wsum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        fq t = red[0];
+#pragma unroll
+        for (int k = 1; k < kThreads / 64; ++k) t = fq_add(t, red[k]);
+        fq_store(&partials[blockIdx.x], t);
+    }
+}
+
+// The same contraction with the table operand loaded STRAIGHT INTO REGISTERS in the matrix instruction's layout (no LDS ring for the
+// table, no barrier in the loop): lane (g, n) of tile nt reads the 16 bytes [16 (g & 1), +16) of output 16 nt + n in row 2 bp + (g >> 1)
+// -- one load instruction covers 2 rows x 512 contiguous bytes -- and the weight fragments come from the (L2-resident) tile buffer
+// the same way.  Steps are software-pipelined S at a time (registers: 2 S x 32 beside the 64 accumulators), every wave runs on its own.
+// tools/probe_streams.hip: this access pattern reads at 6.8-6.9 TB/s with two workgroups per CU, the 1 KiB-per-instruction LDS-DMA
+// ring of the form above at 6.4-6.5 with one.
+template <bool BIG, int S>
+__global__ void __launch_bounds__(kThreads, S == 2 ? 2 : 1) k_multifold_wide_mfma_reg(const fq* __restrict__ src, fq* __restrict__ dst, size_t Lout,
+                                                                          const u32x4* __restrict__ tiles, int m, int log_ob, fq kfix,
+                                                                          fq* __restrict__ partials) {
+    __shared__ u64 xch[kThreads / 64][16 * 17 + 1]; // per wave: the 64-bit partial sums of 16 outputs x 16 words (+1: padding)
+    __shared__ fq red[kThreads / 64];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = lane >> 4, n = lane & 15;
+    const unsigned gpb = gridDim.x >> log_ob;
+    const unsigned c = blockIdx.x / gpb, wi = blockIdx.x % gpb;
+    const size_t Lb = Lout >> log_ob, j0 = (size_t)c * Lb;
+    const unsigned ngroups = (unsigned)(Lb >> 6), gstride = gpb * (kThreads / 64);
+    const unsigned log_nbp = (unsigned)(m - 1), nbp = 1u << log_nbp; // >= S (m >= 3)
+    const unsigned g0 = wi * (kThreads / 64) + wave;
+    const unsigned mysteps = (g0 < ngroups ? (ngroups - g0 + gstride - 1) / gstride : 0) << log_nbp;
+    // this lane's 16 bytes of row (g >> 1), output n of a group's tile 0; + 32 u32x4 per tile, + 2 Lout per row
+    const u32x4* const lane_src = reinterpret_cast<const u32x4*>(src + (size_t)(g >> 1) * Lout + j0 + n) + (g & 1);
+    const u32x4* const lane_w = tiles + lane;
+
+    v4i Tn[S][4], Wn[S][4];
+    auto load_block = [&](unsigned s0) { // steps s0 .. s0 + S - 1 (one group: nbp is a multiple of S)
+        const unsigned group = g0 + (s0 >> log_nbp) * gstride, bp0 = s0 & (nbp - 1);
+        const u32x4* p = lane_src + ((size_t)group << 7);
+#pragma unroll
+        for (int q = 0; q < S; ++q) {
+            const u32x4* pr = p + (size_t)(2 * (bp0 + q)) * Lout * 2; // rows 2 bp, 2 bp + 1: fq = 2 x 16 bytes
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const u32x4 raw = __builtin_nontemporal_load(pr + 32 * nt);
+                Tn[q][nt] = v4i{(int)raw[0], (int)raw[1], (int)raw[2], (int)raw[3]};
+            }
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const u32x4 w4 = lane_w[((size_t)(bp0 + q) * 4 + mt) * 64];
+                Wn[q][mt] = v4i{(int)w4[0], (int)w4[1], (int)w4[2], (int)w4[3]};
+            }
+        }
+    };
+
+    v4i acc[4][4];
+    fq run = fq_zero();
+    if (mysteps) load_block(0);
+    for (unsigned s0 = 0; s0 < mysteps; s0 += S) {
+        v4i T[S][4], W[S][4];
+#pragma unroll
+        for (int q = 0; q < S; ++q)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                T[q][k] = Tn[q][k] ^ v4i{(int)0x80808080u, (int)0x80808080u, (int)0x80808080u, (int)0x80808080u}; // bytes as a - 128
+                W[q][k] = Wn[q][k];
+            }
+        if (s0 + S < mysteps) load_block(s0 + S);
+#pragma unroll
+        for (int q = 0; q < S; ++q) {
+            const unsigned s = s0 + q, bp = s & (nbp - 1);
+            if (bp == 0) {
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = v4i{1 << 27, 1 << 27, 1 << 27, 1 << 27}; // beta
+            }
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(W[q][mt], T[q][nt], acc[mt][nt], 0, 0, 0);
+            if (bp + 1 == nbp) { // the group is complete: 64 columns per output, spread over four lanes -> one field element per lane
+                u64* x = xch[wave];
+                u64 Sw[16];
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) { // the 16 outputs of tile nt go to lane group g = nt
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) { // columns 16 mt + 4 g + r, r = 0..3: one 64-bit partial at word 4 mt + g
+                        const v4i a = acc[mt][nt];
+                        x[n * 17 + 4 * mt + g] = (u64)(u32)a[0] + ((u64)(u32)a[1] << 8) + ((u64)(u32)a[2] << 16) + ((u64)(u32)a[3] << 24);
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // wave-private exchange: program order, no barrier
+                    if (g == nt) {
+#pragma unroll
+                        for (int w = 0; w < 16; ++w) Sw[w] = x[n * 17 + w];
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
+                u32 v[18];
+                u64 cy = 0;
+#pragma unroll
+                for (int w = 0; w < 16; ++w) {
+                    cy += Sw[w] & 0xffffffffull;
+                    v[w] = (u32)cy;
+                    cy = (cy >> 32) + (Sw[w] >> 32);
+                }
+                v[16] = (u32)cy;
+                v[17] = (u32)(cy >> 32);
+                u64 a28[20];
+#pragma unroll
+                for (int k = 0; k < 20; ++k) { // bits [28 k, 28 k + 28)
+                    const int bit = 28 * k, wd = bit >> 5, sh = bit & 31;
+                    const u64 two = (u64)v[wd] | (wd + 1 < 18 ? (u64)v[wd + 1] << 32 : 0);
+                    a28[k] = (two >> sh) & FQ28_MASK;
+                }
+                const fq o = fq_add(fq28_redc(a28), kfix);
+                const unsigned group = g0 + (s >> log_nbp) * gstride;
+                fq* out = dst + j0 + ((size_t)group << 6) + lane; // lane (g, n) holds output 16 g + n = lane
+                if (BIG) fq_store_stream(out, o); else fq_store(out, o);
+                run = fq_add(run, o);
+            }
+        }
+    }
+    const fq wsum = fq_wave_sum(run);
     if (lane == 0) red[wave] = wsum;
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -836,8 +965,23 @@ int launch_multifold_wide(int m, const void* src, void* dst, size_t Lout, const 
         g_forms |= kFormWideMfma;
 #define ZK_MFMA_LAUNCH(BIGV, KV)                                                                                                        \
     hipLaunchKernelGGL((k_multifold_wide_mfma<BIGV, KV>), dim3(g), dim3(kThreads), 0, st, (const fq*)src, (fq*)dst, Lout, (const u32x4*)wbuf, m, \
-                       log_ob, kfix, (fq*)sums_target(g, log_ob, partials, out))
+                       log_ob, kfix, (fq*)sums_target(g, log_ob, partials, out), spread)
         const int depth = gates.wide_mfma_depth;
+        const int spread = gates.wide_mfma_spread && per % 4 == 0 ? 1 : 0; // the spread mapping tiles windows of 16 groups over 4 workgroups
+        if (gates.wide_mfma_reg) { // the table operand by register loads (k_multifold_wide_mfma_reg), S = 2 or 4 steps per block
+#define ZK_MFMA_REG_LAUNCH(BIGV, SV)                                                                                                    \
+    hipLaunchKernelGGL((k_multifold_wide_mfma_reg<BIGV, SV>), dim3(g), dim3(kThreads), 0, st, (const fq*)src, (fq*)dst, Lout, (const u32x4*)wbuf, \
+                       m, log_ob, kfix, (fq*)sums_target(g, log_ob, partials, out))
+            g_forms |= kFormWideMfmaReg;
+            if (stream_stores) {
+                if (gates.wide_mfma_reg == 2) ZK_MFMA_REG_LAUNCH(true, 2); else ZK_MFMA_REG_LAUNCH(true, 4);
+            } else {
+                if (gates.wide_mfma_reg == 2) ZK_MFMA_REG_LAUNCH(false, 2); else ZK_MFMA_REG_LAUNCH(false, 4);
+            }
+#undef ZK_MFMA_REG_LAUNCH
+            reduce_groups_unless_single(g, log_ob, partials, out, st);
+            return g;
+        }
         if (stream_stores) {
             if (depth == 2) ZK_MFMA_LAUNCH(true, 2); else if (depth == 3) ZK_MFMA_LAUNCH(true, 3); else ZK_MFMA_LAUNCH(true, 4);
         } else {
