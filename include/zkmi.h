@@ -386,9 +386,7 @@ int zk_ctx_set_dma_gates(zk_ctx *ctx, int sums_from_log, int wide_stream_from_lo
 /* Wide fold passes with at least 2^from_log outputs (default 15; 64 = never) run their contraction on the matrix cores
  * (v_mfma_i32_16x16x64_i8 over the raw table bytes and signed radix-256 digits of the eq weights) instead
  * of the vector ALU; workgroups_per_cu (1..8) sizes its grid, depth (2..4) is the number of steps (4 KiB of table rows per
- * wave each) kept in flight (defaults 1 and 2).  depth 12..14: the same with a workgroup's waves on groups 8 KiB apart; 22 / 24: the
- * table operand by register loads in the matrix instruction's layout, 2 / 4 steps per block (measured alternatives, DESIGN.md
- * section 9; neither is faster than the default).  Proof bytes do not depend on it. */
+ * wave each) kept in flight (defaults 1 and 2).  Proof bytes do not depend on it. */
 int zk_ctx_set_wide_mfma(zk_ctx *ctx, int from_log, int workgroups_per_cu, int depth);
 /* Which kernel forms the launches of the calling thread took since the last reset (bit mask, ZK_FORM_*): lets a test
  * assert that the form it forced is the one that ran. */

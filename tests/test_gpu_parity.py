@@ -515,7 +515,7 @@ def test_upload_rejects_limbs_that_are_not_fully_reduced():
 # ---- the wide pass on the matrix cores (k_multifold_wide_mfma): same field elements as every other form ------------------
 @pytest.mark.parametrize("log_n,wide,min_log_out,fold_batch", [(14, 6, 8, 2), (16, 8, 8, 2), (17, 8, 9, 3), (18, 8, 10, 4), (20, 8, 12, 4),
                                                                (20, 7, 13, 4), (19, 5, 14, 2), (13, 5, 8, 2), (22, 8, 14, 4)])
-@pytest.mark.parametrize("stream_stores,wg_per_cu,depth", [(False, 2, 2), (True, 1, 3), (True, 1, 4), (False, 2, 12), (True, 1, 13), (False, 2, 22), (True, 1, 24), (True, 4, 22), (False, 1, 32), (True, 1, 34)])
+@pytest.mark.parametrize("stream_stores,wg_per_cu,depth", [(False, 2, 2), (True, 1, 3), (True, 1, 4)])
 def test_sumcheck_mfma_wide_fold_vs_oracle(log_n, wide, min_log_out, fold_batch, stream_stores, wg_per_cu, depth):
     c = zk_amd.Context(0)
     c.set_dma_gates(27, 0 if stream_stores else 64, 22)
@@ -529,9 +529,6 @@ def test_sumcheck_mfma_wide_fold_vs_oracle(log_n, wide, min_log_out, fold_batch,
     proof, ch = zk_amd.SumcheckProver.generate_sumcheck_proof(poly, return_challenges=True)
     forms = c.forms_used()
     assert "wide_mfma" in forms and not forms & {"wide_dma", "wide_dma_stream", "wide_lds", "coop"}, forms
-    assert ("wide_mfma_reg" in forms) == (depth in (22, 24)), forms     # 22, 24: the table operand by register loads
-    if depth >= 32 and (log_n, wide, fold_batch) == (22, 8, 4):     # 2^14 outputs in blocks of 2^10: whole windows of eight groups
-        assert "wide_mfma_il" in forms, forms
     oclaim, ocoeffs, och = O.sumcheck_prove(table) if log_n <= 16 else O.sumcheck_prove_fast(table)
     assert list(proof.initial_claim_sum) == list(oclaim)
     assert np.array_equal(proof.round_polys, ocoeffs)
@@ -539,27 +536,6 @@ def test_sumcheck_mfma_wide_fold_vs_oracle(log_n, wide, min_log_out, fold_batch,
     if log_n <= 16:
         pts = [r for r in ch]
         assert np.array_equal(poly.evaluate(pts).get_evaluation_points(), O.mle_evaluate(table, pts))
-
-
-@pytest.mark.parametrize("depth", [12, 14, 22, 24, 32, 33, 34])
-@pytest.mark.parametrize("log_n", [22, 24, 25])
-def test_mfma_wide_fold_spread_groups_vs_oracle(log_n, depth):
-    """The matrix-core wide fold with its workgroups' waves on groups 8 KiB apart (depth 12..14 = 2..4 with the spread mapping), and
-    with the table operand loaded straight into registers (22, 24), on tables of benchmark-like shape: same proof as the fast
-    oracle and as the packed LDS-DMA form."""
-    table = O.gen_table(SEED + 610 + log_n, 1, 1 << log_n)
-    oclaim, ocoeffs, och = O.sumcheck_prove_fast(table)
-    for d in (depth, depth % 10):
-        c = zk_amd.Context(0)
-        c.set_wide_mfma(0, 2 if d == 22 else 1, d)
-        poly = MLE(table, ctx=c)
-        c.forms_used()
-        proof, ch = zk_amd.SumcheckProver.generate_sumcheck_proof(poly, return_challenges=True)
-        forms = c.forms_used()
-        # 32..34: four groups per wave, interleaved -- for output blocks of whole windows of eight groups (2^25 entries and up here)
-        assert "wide_mfma" in forms and ("wide_mfma_il" in forms) == (d >= 32 and log_n >= 25), forms
-        assert list(proof.initial_claim_sum) == list(oclaim)
-        assert np.array_equal(proof.round_polys, ocoeffs) and np.array_equal(ch, och)
 
 
 @pytest.mark.parametrize("fill", ["p-1", "zero", "one", "byte80", "byteff"])

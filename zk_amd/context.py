@@ -9,7 +9,7 @@ KERNELS = {"block_sums": 0, "multifold": 1, "fold": 2, "eval3": 3, "fold4_eval3"
 
 
 FORMS = ["sums_dma", "sums_reg", "wide_dma", "wide_dma_stream", "wide_reg", "wide_lds", "coop", "fold2_dma", "fold2_reg", "sum9_lazy", "sum9",
-         "fold2_sum9", "wide_mfma", "sum9_mfma", "cross64", "fold3_dma", "fold3_cross64", "fold3_cross64_mfma", "fold_sum27", "fold3_reg", "pwq", "sum27_first", "wide_mfma_reg", "wide_mfma_il"]
+         "fold2_sum9", "wide_mfma", "sum9_mfma", "cross64", "fold3_dma", "fold3_cross64", "fold3_cross64_mfma", "fold_sum27", "fold3_reg", "pwq", "sum27_first"]
 
 
 class Context:

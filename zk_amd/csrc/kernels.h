@@ -42,8 +42,6 @@ enum Form : unsigned {
     kFormFold3Reg = 1u << 19,     // k_fold3_tables (small tables: the three-variable fold of all four tables in one launch)
     kFormPwq = 1u << 20,          // k_fold_sum27<M, PWQ = true>: the product-plus-linear-term form of the GKR phases (the constant-one factor is never read)
     kFormSum27First = 1u << 21,   // k_fold_sum27<0, .>: the first pass of a prove as 27 sums (three rounds) instead of nine
-    kFormWideMfmaReg = 1u << 22,  // k_multifold_wide_mfma_reg (the matrix-core wide pass with register loads)
-    kFormWideMfmaIl = 1u << 23,   // k_multifold_wide_mfma_il (the matrix-core wide pass, four interleaved groups per wave)
 };
 extern thread_local unsigned g_forms;
 // Size thresholds of the LDS-DMA forms (log2 of entries; defaults = the measured break-even points)
@@ -55,9 +53,6 @@ struct DmaGates {
     int wide_mfma_wg_per_cu = 1;   // its grid: workgroups per CU (1 and 2 measure alike; LDS admits two at depth 2)
     int sum9_mfma_from_log = 22;   // nine sums on the matrix cores (k_sum16_mfma) from 2^k quarter-entries (measured break-even); 64 = never
     int wide_mfma_depth = 2;       // its pipeline depth K (2..4): table rows of K steps in flight per wave
-    int wide_mfma_spread = 0;      // wide fold on the matrix cores: a workgroup's waves take groups 8 KiB apart (four memory stacks in flight) instead of four consecutive ones
-    int wide_mfma_reg = 0;         // wide fold on the matrix cores: the table operand by register loads in the operand layout (k_multifold_wide_mfma_reg), 2 or 4 steps per block; 0 = the LDS-DMA ring
-    int wide_mfma_interleave = 0;  // wide fold on the matrix cores: every wave walks four groups 4 KiB apart interleaved (k_multifold_wide_mfma_il: its loads in flight fall on four memory stacks)
     int deg2_triple_from_log = 21; // degree-2 prover: three rounds per pass (k_cross64_mfma + m = 3 fold) on tables of >= 2^k entries; 64 = never.
                                    // A pass that FOLLOWS a three-round pass (the fused fold + cross sums) keeps the form down to results of
                                    // 2^(k-1) entries: 4 x 2^26 prove 3.93 -> 3.90 ms, 2^23 0.80 -> 0.78; a FIRST pass at 2^20 loses (GKR layers 10.1 -> 11.3 ms)

@@ -372,7 +372,7 @@ __global__ void __launch_bounds__(kThreads) k_eq_weights_mfma(ChalWide ch, int m
 template <bool BIG, int K>
 __global__ void __launch_bounds__(kThreads) k_multifold_wide_mfma(const fq* __restrict__ src, fq* __restrict__ dst, size_t Lout,
                                                                    const u32x4* __restrict__ tiles, int m, int log_ob, fq kfix,
-                                                                   fq* __restrict__ partials, int spread) {
+                                                                   fq* __restrict__ partials) {
     constexpr int NP = K + 2, NW = K + 1; // step j issues W(j + K), R(j + K + 1)
     __shared__ u32x4 ring[kThreads / 64][NP][2][128]; // per wave: NP steps x 2 table rows x 2 KiB
     __shared__ u32x4 wring[NW][4][64];                // per workgroup: NW steps x 4 column tiles x 1 KiB
@@ -384,12 +384,8 @@ __global__ void __launch_bounds__(kThreads) k_multifold_wide_mfma(const fq* __re
     const size_t Lb = Lout >> log_ob, j0 = (size_t)c * Lb;
     const unsigned ngroups = (unsigned)(Lb >> 6), gstride = gpb * (kThreads / 64);
     const unsigned nbp = 1u << (m - 1);
-    // Which groups (64 outputs = 2 KiB of every row) a workgroup's four waves take.  Packed: four consecutive groups, 8 KiB of each
-    // row -- every load the workgroup has in flight (rows 2 bp .. of ONE 8 KiB window, the rows 32 MiB apart) then falls on the same
-    // two of the eight memory stacks (address bits 12-14; tools/probe_streams.hip: 6.4 TB/s for that pattern, 6.9-7.1 spread out).
-    // Spread: groups 4 KiB x 2 apart (wave w: first + 4 w inside a window of 16 groups that four workgroups share), four stacks.
-    const unsigned first = spread ? (wi >> 2) * 16 + (wi & 3) : wi * (kThreads / 64); // wave 0's group: the smallest, so it has the most steps
-    const unsigned g0 = first + (spread ? 4 * wave : wave);
+    const unsigned first = wi * (kThreads / 64); // the workgroup's first group: wave 0's, which has the most
+    const unsigned g0 = first + wave;
     const unsigned mysteps = (g0 < ngroups ? (ngroups - g0 + gstride - 1) / gstride : 0) * nbp;
     const unsigned wgsteps = (first < ngroups ? (ngroups - first + gstride - 1) / gstride : 0) * nbp;
 
@@ -508,304 +504,6 @@ __global__ void __launch_bounds__(kThreads) k_multifold_wide_mfma(const fq* __re
     const fq wsum = fq_wave_sum(run);
     __syncthreads();
     fq* red = reinterpret_cast<fq*>(&wring[0][0][0]);
-    if (lane == 0) red[wave] = wsum;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        fq t = red[0];
-#pragma unroll
-        for (int k = 1; k < kThreads / 64; ++k) t = fq_add(t, red[k]);
-        fq_store(&partials[blockIdx.x], t);
-    }
-}
-
-// The same kernel with every wave walking G groups INTERLEAVED (G accumulator sets: 64 G registers, one wave per SIMD): see the
-// comment at the group mapping below.  The pipeline (rings, counted waits, one barrier per step) is unchanged; at the end of a
-// window G consecutive steps finish a group each, so up to 2 G store instructions are younger than the rows a wait is counted
-// for -- the counted wait then waits for a few instructions more than it needs, never fewer.
-template <bool BIG, int K, int G>
-__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))) k_multifold_wide_mfma_il(const fq* __restrict__ src, fq* __restrict__ dst, size_t Lout,
-                                                                   const u32x4* __restrict__ tiles, int m, int log_ob, fq kfix,
-                                                                      fq* __restrict__ partials) {
-    constexpr int NP = K + 2, NW = K + 1; // step j issues W(j + K), R(j + K + 1)
-    __shared__ u32x4 ring[kThreads / 64][NP][2][128]; // per wave: NP steps x 2 table rows x 2 KiB
-    __shared__ u32x4 wring[NW][4][64];                // per workgroup: NW steps x 4 column tiles x 1 KiB
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int g = lane >> 4, n = lane & 15;
-    const unsigned gpb = gridDim.x >> log_ob;
-    const unsigned c = blockIdx.x / gpb, wi = blockIdx.x % gpb;
-    const size_t Lb = Lout >> log_ob, j0 = (size_t)c * Lb;
-    const unsigned ngroups = (unsigned)(Lb >> 6), gstride = gpb * (kThreads / 64) * G;
-    const unsigned nbp = 1u << (m - 1);
-    // A wave owns G groups 4 KiB apart at a time (a window of 2 G groups = G x 4 KiB of every row, shared with its neighbour wave, which
-    // takes the other 2 KiB half of each 4 KiB) and walks them INTERLEAVED: step s = (u, k), u = s / G, k = s % G: rows 2 bp, 2 bp + 1
-    // (bp = u % nbp) of group g0 + (u / nbp) gstride + 2 k, accumulated in set k.  The loads a wave has in flight then fall on G different
-    // memory stacks (address bits 12-14) instead of one: the rows of one group are 32 MiB apart and alias (tools/probe_streams.hip).
-    // ngroups is a multiple of 2 G (the launcher checks), so a window is whole or absent.
-    const unsigned first = (2 * wi) * 2 * G;                                  // wave 0's window: the smallest index, so it has the most steps
-    const unsigned g0 = (2 * wi + (wave >> 1)) * 2 * G + (wave & 1);
-    const unsigned mysteps = (g0 < ngroups ? (ngroups - g0 + gstride - 1) / gstride : 0) * nbp * G;
-    const unsigned wgsteps = (first < ngroups ? (ngroups - first + gstride - 1) / gstride : 0) * nbp * G;
-
-    auto issue_rows = [&](unsigned s) { // R(s): rows 2 bp, 2 bp + 1 of step s's group; four DMA instructions
-        const unsigned u = s / G, group = g0 + (u / nbp) * gstride + 2 * (s % G), bp = u % nbp;
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const u32x4* p = reinterpret_cast<const u32x4*>(src + (size_t)(2 * bp + r) * Lout + j0 + ((size_t)group << 6)) + lane;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
-                                             (__attribute__((address_space(3))) void*)&ring[wave][s % NP][r][0], 16, 0, 2);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p + 64),
-                                             (__attribute__((address_space(3))) void*)&ring[wave][s % NP][r][64], 16, 0, 2);
-        }
-    };
-    auto issue_tile = [&](unsigned s) { // W(s): this wave's quarter (column tile mt = wave) of step s's weight tiles; one DMA instruction
-        const u32x4* p = tiles + ((size_t)((s / G) % nbp) * 4 + wave) * 64 + lane;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
-                                         (__attribute__((address_space(3))) void*)&wring[s % NW][wave][0], 16, 0, 0);
-    };
-
-    v4i acc[G][4][4];
-    fq run = fq_zero();
-#pragma unroll
-    for (int q = 0; q < K; ++q) {
-        if ((unsigned)q < mysteps) issue_rows(q);
-        if ((unsigned)q < wgsteps) issue_tile(q);
-    }
-    if ((unsigned)K < mysteps) issue_rows(K);
-    bool stored = false;
-    for (unsigned sb = 0; sb < wgsteps; sb += G) {
-#pragma unroll
-    for (int kk = 0; kk < G; ++kk) { // the accumulator set is a compile-time index
-        const unsigned s = sb + kk;
-        const bool active = s < mysteps; // wave-uniform
-        if (active && s + K < mysteps) { // R(s+1) .. R(s+K) and W(s+1) .. W(s+K-1) may stay in flight: 5 K - 1 instructions
-            if (stored) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * K + 1) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * K - 1) : "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the last two steps of a wave, and empty steps: drain
-        }
-        stored = false;
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        const unsigned bp = (s / G) % nbp;
-        v4i T[4], W[4];
-        if (active) {
-            if (bp == 0) {
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < 4; ++nt) acc[kk][mt][nt] = v4i{1 << 27, 1 << 27, 1 << 27, 1 << 27}; // beta
-            }
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) { // the table operand: 16 outputs x (2 rows x 32 bytes) per tile, bytes presented as a - 128
-                const u32x4 raw = ring[wave][s % NP][g >> 1][2 * (16 * nt + n) + (g & 1)];
-                T[nt] = v4i{(int)(raw[0] ^ 0x80808080u), (int)(raw[1] ^ 0x80808080u), (int)(raw[2] ^ 0x80808080u), (int)(raw[3] ^ 0x80808080u)};
-            }
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                const u32x4 w4 = wring[s % NW][mt][lane];
-                W[mt] = v4i{(int)w4[0], (int)w4[1], (int)w4[2], (int)w4[3]};
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // operands in registers before their slots are refilled
-        }
-        if (s + K < wgsteps) issue_tile(s + K);
-        const bool last = active && bp + 1 == nbp;
-        if (active && !last && s + K + 1 < mysteps) issue_rows(s + K + 1);
-        if (active) {
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt) acc[kk][mt][nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(W[mt], T[nt], acc[kk][mt][nt], 0, 0, 0);
-        }
-        if (last) { // the group is complete: 64 columns per output, spread over four lanes -> one field element per lane
-            u64* x = reinterpret_cast<u64*>(&ring[wave][s % NP][0][0]); // the slot this step just read: 4 KiB of exchange space
-            u64 S[16];
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) { // the 16 outputs of tile nt go to lane group g = nt
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt) { // columns 16 mt + 4 g + r, r = 0..3: one 64-bit partial at word 4 mt + g
-                    const v4i a = acc[kk][mt][nt];
-                    x[n * 17 + 4 * mt + g] = (u64)(u32)a[0] + ((u64)(u32)a[1] << 8) + ((u64)(u32)a[2] << 16) + ((u64)(u32)a[3] << 24);
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // wave-private exchange: program order, no barrier
-                if (g == nt) {
-#pragma unroll
-                    for (int w = 0; w < 16; ++w) S[w] = x[n * 17 + w];
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            }
-            if (s + K + 1 < mysteps) issue_rows(s + K + 1); // the slot is free again
-            // V = sum_w S[w] 2^(32 w), S[w] < 2^53: 18 words, then 28-bit columns for the reduction
-            u32 v[18];
-            u64 cy = 0;
-#pragma unroll
-            for (int w = 0; w < 16; ++w) {
-                cy += S[w] & 0xffffffffull;
-                v[w] = (u32)cy;
-                cy = (cy >> 32) + (S[w] >> 32);
-            }
-            v[16] = (u32)cy;
-            v[17] = (u32)(cy >> 32);
-            u64 a28[20];
-#pragma unroll
-            for (int k = 0; k < 20; ++k) { // bits [28 k, 28 k + 28)
-                const int bit = 28 * k, wd = bit >> 5, sh = bit & 31;
-                const u64 two = (u64)v[wd] | (wd + 1 < 18 ? (u64)v[wd + 1] << 32 : 0);
-                a28[k] = (two >> sh) & FQ28_MASK;
-            }
-            const fq o = fq_add(fq28_redc(a28), kfix);
-            const unsigned group = g0 + ((s / G) / nbp) * gstride + 2 * kk;
-            fq* out = dst + j0 + ((size_t)group << 6) + lane; // lane (g, n) holds output 16 g + n = lane
-            if (BIG) fq_store_stream(out, o); else fq_store(out, o);
-            stored = true;
-            run = fq_add(run, o);
-        }
-    }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const fq wsum = fq_wave_sum(run);
-    __syncthreads();
-    fq* red = reinterpret_cast<fq*>(&wring[0][0][0]);
-    if (lane == 0) red[wave] = wsum;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        fq t = red[0];
-#pragma unroll
-        for (int k = 1; k < kThreads / 64; ++k) t = fq_add(t, red[k]);
-        fq_store(&partials[blockIdx.x], t);
-    }
-}
-
-// The same contraction with the table operand loaded STRAIGHT INTO REGISTERS in the matrix instruction's layout (no LDS ring for the
-// table): lane (g, n) of tile nt reads the 16 bytes [16 (g & 1), +16) of output 16 nt + n in row 2 bp + (g >> 1) -- one load instruction
-// covers 2 rows x 512 contiguous bytes.  The four waves of a workgroup walk the b-pairs in lockstep (one barrier per step) and share the
-// weight tiles through a two-slot LDS ring: wave w loads its quarter of W(s + 2) into a register at step s and writes the quarter of
-// W(s + 1) it holds into the slot step s - 1 read -- plain loads and LDS writes, so every wait is the compiler's.  Table steps are
-// software-pipelined S at a time (2 S x 16 registers beside the 64 accumulators).
-// tools/probe_streams.hip: this access pattern reads at 6.7-6.9 TB/s, the 1 KiB-per-instruction LDS-DMA ring of the form above at
-// 6.4-6.5.  (A first version that also pulled the weight fragments through the vector memory path per wave ran at 5.9.)
-template <bool BIG, int S>
-__global__ void __launch_bounds__(kThreads, S == 2 ? 2 : 1) k_multifold_wide_mfma_reg(const fq* __restrict__ src, fq* __restrict__ dst, size_t Lout,
-                                                                          const u32x4* __restrict__ tiles, int m, int log_ob, fq kfix,
-                                                                          fq* __restrict__ partials) {
-    __shared__ u32x4 wring[2][4][64];               // per workgroup: 2 steps x 4 column tiles x 1 KiB
-    __shared__ u64 xch[kThreads / 64][16 * 17 + 1]; // per wave: the 64-bit partial sums of 16 outputs x 16 words (+1: padding)
-    __shared__ fq red[kThreads / 64];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int g = lane >> 4, n = lane & 15;
-    const unsigned gpb = gridDim.x >> log_ob;
-    const unsigned c = blockIdx.x / gpb, wi = blockIdx.x % gpb;
-    const size_t Lb = Lout >> log_ob, j0 = (size_t)c * Lb;
-    const unsigned ngroups = (unsigned)(Lb >> 6), gstride = gpb * (kThreads / 64);
-    const unsigned log_nbp = (unsigned)(m - 1), nbp = 1u << log_nbp; // >= S (m >= 3)
-    const unsigned first = wi * (kThreads / 64); // the workgroup's first group: wave 0's, which has the most
-    const unsigned g0 = first + wave;
-    const unsigned mysteps = (g0 < ngroups ? (ngroups - g0 + gstride - 1) / gstride : 0) << log_nbp;
-    const unsigned wgsteps = (first < ngroups ? (ngroups - first + gstride - 1) / gstride : 0) << log_nbp;
-    // this lane's 16 bytes of row (g >> 1), output n of a group's tile 0; + 32 u32x4 per tile, + 2 Lout per row
-    const u32x4* const lane_src = reinterpret_cast<const u32x4*>(src + (size_t)(g >> 1) * Lout + j0 + n) + (g & 1);
-    const u32x4* const lane_w = tiles + (size_t)wave * 64 + lane; // this wave's quarter (column tile mt = wave) of a b-pair's tiles: + 256 per b-pair
-
-    v4i Tn[S][4];
-    auto load_block = [&](unsigned s0) { // table operands of steps s0 .. s0 + S - 1 (one group: nbp is a multiple of S)
-        const unsigned group = g0 + (s0 >> log_nbp) * gstride, bp0 = s0 & (nbp - 1);
-        const u32x4* p = lane_src + ((size_t)group << 7);
-#pragma unroll
-        for (int q = 0; q < S; ++q) {
-            const u32x4* pr = p + (size_t)(2 * (bp0 + q)) * Lout * 2; // rows 2 bp, 2 bp + 1: fq = 2 x 16 bytes
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-                const u32x4 raw = __builtin_nontemporal_load(pr + 32 * nt);
-                Tn[q][nt] = v4i{(int)raw[0], (int)raw[1], (int)raw[2], (int)raw[3]};
-            }
-        }
-    };
-
-    v4i acc[4][4];
-    fq run = fq_zero();
-    u32x4 wq = {0, 0, 0, 0}; // this wave's quarter of the NEXT step's weight tiles
-    if (wgsteps) {
-        wring[0][wave][lane] = lane_w[0];
-        if (wgsteps > 1) wq = lane_w[(size_t)(1 & (nbp - 1)) * 256];
-    }
-    if (mysteps) load_block(0);
-    for (unsigned s0 = 0; s0 < wgsteps; s0 += S) { // wgsteps is a multiple of nbp, hence of S
-        const bool active = s0 < mysteps;          // wave-uniform; a whole block is active or not
-        v4i T[S][4];
-        if (active) {
-#pragma unroll
-            for (int q = 0; q < S; ++q)
-#pragma unroll
-                for (int k = 0; k < 4; ++k) T[q][k] = Tn[q][k] ^ v4i{(int)0x80808080u, (int)0x80808080u, (int)0x80808080u, (int)0x80808080u}; // bytes as a - 128
-            if (s0 + S < mysteps) load_block(s0 + S);
-        }
-#pragma unroll
-        for (int q = 0; q < S; ++q) {
-            const unsigned s = s0 + q, bp = s & (nbp - 1);
-            __syncthreads(); // W(s) is in wring[s & 1]; every wave has finished reading wring[(s + 1) & 1] (step s - 1)
-            v4i W[4];
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                const u32x4 w4 = wring[s & 1][mt][lane];
-                W[mt] = v4i{(int)w4[0], (int)w4[1], (int)w4[2], (int)w4[3]};
-            }
-            if (s + 1 < wgsteps) wring[(s + 1) & 1][wave][lane] = wq;
-            if (s + 2 < wgsteps) wq = lane_w[(size_t)((s + 2) & (nbp - 1)) * 256];
-            if (!active) continue;
-            if (bp == 0) {
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = v4i{1 << 27, 1 << 27, 1 << 27, 1 << 27}; // beta
-            }
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(W[mt], T[q][nt], acc[mt][nt], 0, 0, 0);
-            if (bp + 1 == nbp) { // the group is complete: 64 columns per output, spread over four lanes -> one field element per lane
-                u64* x = xch[wave];
-                u64 Sw[16];
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt) { // the 16 outputs of tile nt go to lane group g = nt
-#pragma unroll
-                    for (int mt = 0; mt < 4; ++mt) { // columns 16 mt + 4 g + r, r = 0..3: one 64-bit partial at word 4 mt + g
-                        const v4i a = acc[mt][nt];
-                        x[n * 17 + 4 * mt + g] = (u64)(u32)a[0] + ((u64)(u32)a[1] << 8) + ((u64)(u32)a[2] << 16) + ((u64)(u32)a[3] << 24);
-                    }
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // wave-private exchange: program order, no barrier
-                    if (g == nt) {
-#pragma unroll
-                        for (int w = 0; w < 16; ++w) Sw[w] = x[n * 17 + w];
-                    }
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                }
-                u32 v[18];
-                u64 cy = 0;
-#pragma unroll
-                for (int w = 0; w < 16; ++w) {
-                    cy += Sw[w] & 0xffffffffull;
-                    v[w] = (u32)cy;
-                    cy = (cy >> 32) + (Sw[w] >> 32);
-                }
-                v[16] = (u32)cy;
-                v[17] = (u32)(cy >> 32);
-                u64 a28[20];
-#pragma unroll
-                for (int k = 0; k < 20; ++k) { // bits [28 k, 28 k + 28)
-                    const int bit = 28 * k, wd = bit >> 5, sh = bit & 31;
-                    const u64 two = (u64)v[wd] | (wd + 1 < 18 ? (u64)v[wd + 1] << 32 : 0);
-                    a28[k] = (two >> sh) & FQ28_MASK;
-                }
-                const fq o = fq_add(fq28_redc(a28), kfix);
-                const unsigned group = g0 + (s >> log_nbp) * gstride;
-                fq* out = dst + j0 + ((size_t)group << 6) + lane; // lane (g, n) holds output 16 g + n = lane
-                if (BIG) fq_store_stream(out, o); else fq_store(out, o);
-                run = fq_add(run, o);
-            }
-        }
-    }
-    const fq wsum = fq_wave_sum(run);
     if (lane == 0) red[wave] = wsum;
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -1138,41 +836,8 @@ int launch_multifold_wide(int m, const void* src, void* dst, size_t Lout, const 
         g_forms |= kFormWideMfma;
 #define ZK_MFMA_LAUNCH(BIGV, KV)                                                                                                        \
     hipLaunchKernelGGL((k_multifold_wide_mfma<BIGV, KV>), dim3(g), dim3(kThreads), 0, st, (const fq*)src, (fq*)dst, Lout, (const u32x4*)wbuf, m, \
-                       log_ob, kfix, (fq*)sums_target(g, log_ob, partials, out), spread)
+                       log_ob, kfix, (fq*)sums_target(g, log_ob, partials, out))
         const int depth = gates.wide_mfma_depth;
-        const int spread = gates.wide_mfma_spread && per % 4 == 0 ? 1 : 0; // the spread mapping tiles windows of 16 groups over 4 workgroups
-        if (gates.wide_mfma_interleave && ((Lout >> log_ob) / 64) % 8 == 0) { // every wave walks four groups interleaved (k_multifold_wide_mfma_il)
-            size_t per_il = ((Lout >> log_ob) / 64 + 15) / 16; // a workgroup takes two windows of 2 G = 8 groups at a time
-            if (per_il > cap) per_il = cap;
-            if (per_il < 1) per_il = 1;
-            const int gi = (int)(per_il << log_ob);
-#define ZK_MFMA_IL_LAUNCH(BIGV, KV)                                                                                                     \
-    hipLaunchKernelGGL((k_multifold_wide_mfma_il<BIGV, KV, 4>), dim3(gi), dim3(kThreads), 0, st, (const fq*)src, (fq*)dst, Lout, (const u32x4*)wbuf, \
-                       m, log_ob, kfix, (fq*)sums_target(gi, log_ob, partials, out))
-            g_forms |= kFormWideMfmaIl;
-            if (stream_stores) {
-                if (depth == 2) ZK_MFMA_IL_LAUNCH(true, 2); else if (depth == 3) ZK_MFMA_IL_LAUNCH(true, 3); else ZK_MFMA_IL_LAUNCH(true, 4);
-            } else {
-                if (depth == 2) ZK_MFMA_IL_LAUNCH(false, 2); else if (depth == 3) ZK_MFMA_IL_LAUNCH(false, 3); else ZK_MFMA_IL_LAUNCH(false, 4);
-            }
-#undef ZK_MFMA_IL_LAUNCH
-            reduce_groups_unless_single(gi, log_ob, partials, out, st);
-            return gi;
-        }
-        if (gates.wide_mfma_reg) { // the table operand by register loads (k_multifold_wide_mfma_reg), S = 2 or 4 steps per block
-#define ZK_MFMA_REG_LAUNCH(BIGV, SV)                                                                                                    \
-    hipLaunchKernelGGL((k_multifold_wide_mfma_reg<BIGV, SV>), dim3(g), dim3(kThreads), 0, st, (const fq*)src, (fq*)dst, Lout, (const u32x4*)wbuf, \
-                       m, log_ob, kfix, (fq*)sums_target(g, log_ob, partials, out))
-            g_forms |= kFormWideMfmaReg;
-            if (stream_stores) {
-                if (gates.wide_mfma_reg == 2) ZK_MFMA_REG_LAUNCH(true, 2); else ZK_MFMA_REG_LAUNCH(true, 4);
-            } else {
-                if (gates.wide_mfma_reg == 2) ZK_MFMA_REG_LAUNCH(false, 2); else ZK_MFMA_REG_LAUNCH(false, 4);
-            }
-#undef ZK_MFMA_REG_LAUNCH
-            reduce_groups_unless_single(g, log_ob, partials, out, st);
-            return g;
-        }
         if (stream_stores) {
             if (depth == 2) ZK_MFMA_LAUNCH(true, 2); else if (depth == 3) ZK_MFMA_LAUNCH(true, 3); else ZK_MFMA_LAUNCH(true, 4);
         } else {

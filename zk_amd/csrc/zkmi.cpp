@@ -1465,23 +1465,10 @@ int zk_ctx_set_dma_gates(zk_ctx* c, int sums_from_log, int wide_stream_from_log,
     return ZK_OK;
 }
 int zk_ctx_set_wide_mfma(zk_ctx* c, int from_log, int workgroups_per_cu, int depth) {
-    // depth 2..4: the LDS-DMA ring with that many steps in flight; 12..14: the same with the spread group mapping; 22, 24: the table
-    // operand by register loads, 2 or 4 steps per block (k_multifold_wide_mfma_reg)
-    // 32..34: the LDS-DMA ring, depth 2..4, every wave walking four groups interleaved (k_multifold_wide_mfma_il)
-    if (!c) return ZK_E_ARG;
-    int reg = 0;
-    if (depth == 22 || depth == 24) { reg = depth - 20; depth = c->gates.wide_mfma_depth; }
-    const bool interleave = depth >= 32 && depth <= 34;
-    if (interleave) depth -= 30;
-    const bool spread = depth >= 12;
-    if (spread) depth -= 10;
-    if (from_log < 0 || from_log > 64 || workgroups_per_cu < 1 || workgroups_per_cu > 8 || depth < 2 || depth > 4) return ZK_E_ARG;
+    if (!c || from_log < 0 || from_log > 64 || workgroups_per_cu < 1 || workgroups_per_cu > 8 || depth < 2 || depth > 4) return ZK_E_ARG;
     c->gates.wide_mfma_from_log = from_log;
     c->gates.wide_mfma_wg_per_cu = workgroups_per_cu;
     c->gates.wide_mfma_depth = depth;
-    c->gates.wide_mfma_spread = spread ? 1 : 0;
-    c->gates.wide_mfma_reg = reg;
-    c->gates.wide_mfma_interleave = interleave ? 1 : 0;
     return ZK_OK;
 }
 unsigned zk_ctx_forms_used(zk_ctx* c, int reset) {
