@@ -85,6 +85,9 @@ int zk_transcript_append(zk_transcript *t, const uint8_t *data, size_t len); /* 
 int zk_transcript_sample_challenge(zk_transcript *t, uint64_t out_mont[4]);  /* sample_challenge :28-36 */
 int zk_transcript_sample_n_challenges(zk_transcript *t, size_t n, uint64_t *out_mont); /* :39-41 */
 int zk_transcript_peek_digest(const zk_transcript *t, uint8_t out[32]);    /* Keccak256(all bytes so far) */
+/* The host Keccak-f[1600] exists in two builds of the same source (baseline x86-64; BMI1/BMI2: ANDN, RORX), one chosen per process
+ * by the CPU's features.  Runs BOTH on nblocks pseudo-random rate blocks: 0 = identical states (or a single build), 1 = they differ. */
+int zk_transcript_selftest(size_t nblocks);
 
 /* ---- MultiLinearPolynomial (polynomials/src/multilinear_polynomial/evaluation_form.rs) */
 /* MultiLinearPolynomial::new :22-32 -- copies `len` elements host -> device.  The limbs must be fully reduced (< p, as

@@ -56,6 +56,15 @@ def test_host_transcript_matches_oracle_and_kats():
         assert list(t.sample_challenge()) == list(o.sample())
     got = t.sample_n_challenges(5)
     assert [list(r) for r in got] == [list(o.sample()) for _ in range(5)]
+    # long appends take the whole-block path (several rate blocks per call): still the oracle's digest
+    t, o = zk_amd.Transcript(), O.OTranscript()
+    for n in (136 * 7, 136 * 3 + 5, 5000, 131):
+        data = bytes(rng.randrange(256) for _ in range(n))
+        t.append(data)
+        o.append(data)
+        assert t.peek_digest() == o.peek_digest()
+    # the two builds of the round function (baseline ISA and BMI1/BMI2) agree; a process runs only one of them
+    assert zk_amd.lib().zk_transcript_selftest(64) == 0
 
 
 def test_host_partial_verify_matches_oracle_on_goldens():

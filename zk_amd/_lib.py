@@ -45,6 +45,7 @@ SYMBOLS = [
     ("zk_transcript_sample_challenge", C.c_int, [_VP, u64p]),
     ("zk_transcript_sample_n_challenges", C.c_int, [_VP, C.c_size_t, u64p]),
     ("zk_transcript_peek_digest", C.c_int, [_VP, u8p]),
+    ("zk_transcript_selftest", C.c_int, [C.c_size_t]),
     ("zk_mle_upload_mont", C.c_int, [_VP, u64p, C.c_size_t, C.POINTER(_VP)]),
     ("zk_mle_upload_le32", C.c_int, [_VP, u8p, C.c_size_t, C.POINTER(_VP)]),
     ("zk_mle_wrap_device", C.c_int, [_VP, _VP, C.c_size_t, C.POINTER(_VP)]),

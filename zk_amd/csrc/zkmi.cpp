@@ -130,6 +130,7 @@ int zk_transcript_sample_n_challenges(zk_transcript* t, size_t n, uint64_t* out)
     for (size_t i = 0; i < n; ++i) zkh::store(out + 4 * i, t->sample());
     return ZK_OK;
 }
+int zk_transcript_selftest(size_t nblocks) { return zkh::Keccak256::selftest(nblocks); }
 int zk_transcript_peek_digest(const zk_transcript* t, uint8_t out[32]) {
     if (!t || !out) return ZK_E_ARG;
     t->hasher.peek(out);
