@@ -245,6 +245,7 @@ def main():
     # roofline.traffic: the HBM counter passes run as CHILD processes before this one touches the GPU
     live_traffic = None
     if world == 1 and not args.force_sharded and args.workload in ("mle", "sum2x2") and not args.no_live_traffic:
+        import torch  # noqa: F401  pages the libraries in (minutes on a fresh box) so the children's time limit is not spent on it; importing torch does not initialise the GPU
         live_traffic = live_pmc_traffic(args)
 
     # stdout carries exactly ONE JSON line: libraries (RCCL prints a version banner on fd 1) write to stderr instead

@@ -340,9 +340,14 @@ __global__ void __launch_bounds__(kThreads) k_sum16_mfma(Tab4 T, size_t q, fq* _
 #pragma unroll
         for (int k = 0; k < 16; ++k) mat[((k & 3) + 8 * (k >> 2) + 4 * (lane >> 5)) * 32 + (lane & 31)] = acc[e][k];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        long long d = 0; // D[k], k = lane: the anti-diagonal i + i' = k (lane 63: empty)
-        const int klo = lane > 31 ? lane - 31 : 0, khi = lane < 31 ? lane : 31;
-        for (int i = klo; i <= khi && lane < 63; ++i) d += mat[i * 32 + (lane - i)];
+        // D[k], k = lane: the anti-diagonal i + i' = k of the 32 x 32 matrix (lane 63: empty).  Fixed trip count, in-range addresses,
+        // the bounds as a select: the 32 LDS reads issue back to back (a loop over [klo, khi] waited for every read)
+        long long d = 0;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            const int j = lane - i, v = mat[i * 32 + (j & 31)];
+            d += (j >= 0 && j < 32) ? v : 0;
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         // D[k] * 256^k * 2^-256 mod p: |D| < 2^37 as a field element times the constant, sign restored afterwards
         const bool neg = d < 0;
@@ -552,9 +557,14 @@ __global__ void __launch_bounds__(512) k_cross64_mfma(Tab4 T, size_t q, fq* __re
 #pragma unroll
         for (int k = 0; k < 16; ++k) mat[((k & 3) + 8 * (k >> 2) + 4 * (lane >> 5)) * 32 + (lane & 31)] = a[k];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        long long d = 0; // D[k], k = lane: the anti-diagonal i + i' = k (lane 63: empty)
-        const int klo = lane > 31 ? lane - 31 : 0, khi = lane < 31 ? lane : 31;
-        for (int i = klo; i <= khi && lane < 63; ++i) d += mat[i * 32 + (lane - i)];
+        // D[k], k = lane: the anti-diagonal i + i' = k of the 32 x 32 matrix (lane 63: empty).  Fixed trip count, in-range addresses,
+        // the bounds as a select: the 32 LDS reads issue back to back (a loop over [klo, khi] waited for every read)
+        long long d = 0;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            const int j = lane - i, v = mat[i * 32 + (j & 31)];
+            d += (j >= 0 && j < 32) ? v : 0;
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         const bool neg = d < 0;
         const unsigned long long ad = (unsigned long long)(neg ? -d : d);
@@ -737,9 +747,14 @@ __global__ void __launch_bounds__(512) k_fold3_cross64(Tab4 S, Tab4w Dst, size_t
 #pragma unroll
         for (int k = 0; k < 16; ++k) mat[((k & 3) + 8 * (k >> 2) + 4 * (lane >> 5)) * 32 + (lane & 31)] = a[k];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // the anti-diagonal i + j = lane of the 32 x 32 matrix (lane 63 has none).  Fixed trip count, in-range addresses, the bounds
+        // as a select: the 32 LDS reads issue back to back (a loop over [klo, khi] waited for every read: ~20 us per launch)
         long long d = 0;
-        const int klo = lane > 31 ? lane - 31 : 0, khi = lane < 31 ? lane : 31;
-        for (int i = klo; i <= khi && lane < 63; ++i) d += mat[i * 32 + (lane - i)];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            const int j = lane - i, v = mat[i * 32 + (j & 31)];
+            d += (j >= 0 && j < 32) ? v : 0;
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         const bool neg = d < 0;
         const unsigned long long ad = (unsigned long long)(neg ? -d : d);
@@ -1098,9 +1113,14 @@ k_fold3_cross64_mfma(Tab4 S, Tab4w Dst, size_t outlen, const u32x4* __restrict__
 #pragma unroll
         for (int k = 0; k < 16; ++k) mat[((k & 3) + 8 * (k >> 2) + 4 * (lane >> 5)) * 32 + (lane & 31)] = a[k];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // the anti-diagonal i + j = lane of the 32 x 32 matrix (lane 63 has none).  Fixed trip count, in-range addresses, the bounds
+        // as a select: the 32 LDS reads issue back to back (a loop over [klo, khi] waited for every read: ~20 us per launch)
         long long d = 0;
-        const int klo = lane > 31 ? lane - 31 : 0, khi = lane < 31 ? lane : 31;
-        for (int i = klo; i <= khi && lane < 63; ++i) d += mat[i * 32 + (lane - i)];
+#pragma unroll 8 // eight reads in flight: a full unroll costs this kernel (at its 512-register limit) two more spilled registers
+        for (int i = 0; i < 32; ++i) {
+            const int j = lane - i, v = mat[i * 32 + (j & 31)];
+            d += (j >= 0 && j < 32) ? v : 0;
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         const bool neg = d < 0;
         const unsigned long long ad = (unsigned long long)(neg ? -d : d);
