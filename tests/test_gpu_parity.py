@@ -55,6 +55,21 @@ def test_upload_download_roundtrip_and_to_bytes(ctx):
     assert O.mont_to_ints(m3.get_evaluation_points()) == [v % P for v in raw]
 
 
+@pytest.mark.parametrize("log_n", [15, 16, 19, 20, 21])
+def test_to_bytes_stream_chunks_vs_oracle(log_n):
+    """to_bytes of tables that take one, two and several chunks of the pinned staging stream (a 2^15-entry first chunk, then 2^19-entry
+    ones, alternating between two halves): the oracle's bytes, and the same transcript state when the prover absorbs the table itself."""
+    t = O.gen_table(SEED + 700 + log_n, 0, 1 << log_n)
+    m = MLE(t)
+    want = O.mle_to_bytes(t)
+    assert m.to_bytes() == want
+    tr = zk_amd.Transcript()
+    tr.append(want)
+    claim, coeffs, ch = zk_amd.SumcheckProver.generate_round_polys(m, tr)      # the caller's transcript holds the table's bytes
+    proof, ch2 = zk_amd.SumcheckProver.generate_sumcheck_proof(m, return_challenges=True)   # the library absorbs the table through the stream
+    assert np.array_equal(proof.round_polys, coeffs) and np.array_equal(ch, ch2)
+
+
 def test_new_rejects_non_power_of_two(ctx):
     for n in (3, 5, 6, 12, 1000):
         with pytest.raises(zk_amd.ZkError) as ei:

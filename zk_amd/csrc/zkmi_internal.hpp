@@ -23,6 +23,7 @@ namespace zki {
 constexpr size_t kElem = 32;
 constexpr size_t kChunkElems = (size_t)1 << 21; // 64 MiB staging chunks for byte conversion
 constexpr size_t kLeChunkElems = (size_t)1 << 19; // to_bytes: 16 MiB halves of the pinned staging buffer
+constexpr size_t kLeFirstElems = (size_t)1 << 15; // ... and a 1 MiB first chunk (stream_le32)
 constexpr size_t kSums = (size_t)1 << zkk::kMaxFoldBatch; // block sums per pass
 constexpr size_t kHostTail = 64;                // degree-2 prover: tables of <= this many entries are finished on the host
 constexpr size_t kFold3SmallBelow = (size_t)1 << 12; // degree-2 prover: three-variable folds with fewer outputs per table run as one launch (k_fold3_tables)
@@ -288,9 +289,17 @@ int stream_le32(zk_ctx* c, const void* table, size_t len, Sink&& sink) {
         HIPCHK(c, hipEventCreateWithFlags(&c->le_ev[0], hipEventDisableTiming));
         HIPCHK(c, hipEventCreateWithFlags(&c->le_ev[1], hipEventDisableTiming));
     }
-    const size_t nchunks = (len + kLeChunkElems - 1) / kLeChunkElems;
+    // chunk 0 is SHORT (1 MiB): nothing can be consumed before the first chunk has crossed PCIe (16 MiB: 0.3 ms of a 45 ms absorb with
+    // the host idle); from then on the device side hides under the sink.  Chunk i > 0 covers [kLeFirstElems + (i - 1) kLeChunkElems, ...)
+    const size_t first = std::min(len, kLeFirstElems);
+    const size_t nchunks = len ? 1 + (len - first + kLeChunkElems - 1) / kLeChunkElems : 0;
+    auto span = [&](size_t i, size_t* off, size_t* n) {
+        *off = i == 0 ? 0 : first + (i - 1) * kLeChunkElems;
+        *n = i == 0 ? first : std::min(kLeChunkElems, len - *off);
+    };
     auto convert = [&](size_t i) -> int {
-        const size_t off = i * kLeChunkElems, n = std::min(kLeChunkElems, len - off);
+        size_t off, n;
+        span(i, &off, &n);
         zkk::launch_to_le32((const uint8_t*)table + off * kElem, (uint8_t*)c->le_host_dev + (i & 1) * kLeChunkElems * kElem, n, c->stream);
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipEventRecord(c->le_ev[i & 1], c->stream));
@@ -301,7 +310,8 @@ int stream_le32(zk_ctx* c, const void* table, size_t len, Sink&& sink) {
     for (size_t i = 0; i < nchunks; ++i) {
         if (i + 1 < nchunks && (rc = convert(i + 1))) return rc; // its half was consumed by the sink one iteration ago
         HIPCHK(c, hipEventSynchronize(c->le_ev[i & 1]));
-        const size_t off = i * kLeChunkElems, n = std::min(kLeChunkElems, len - off);
+        size_t off, n;
+        span(i, &off, &n);
         sink(c->le_host + (i & 1) * kLeChunkElems * kElem, n * kElem, off);
     }
     return ZK_OK;
