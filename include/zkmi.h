@@ -85,8 +85,9 @@ int zk_transcript_append(zk_transcript *t, const uint8_t *data, size_t len); /* 
 int zk_transcript_sample_challenge(zk_transcript *t, uint64_t out_mont[4]);  /* sample_challenge :28-36 */
 int zk_transcript_sample_n_challenges(zk_transcript *t, size_t n, uint64_t *out_mont); /* :39-41 */
 int zk_transcript_peek_digest(const zk_transcript *t, uint8_t out[32]);    /* Keccak256(all bytes so far) */
-/* The host Keccak-f[1600] exists in two builds of the same source (baseline x86-64; BMI1/BMI2: ANDN, RORX), one chosen per process
- * by the CPU's features.  Runs BOTH on nblocks pseudo-random rate blocks: 0 = identical states (or a single build), 1 = they differ. */
+/* The host Keccak-f[1600] exists in three builds of the round function -- baseline x86-64; BMI1/BMI2 (ANDN, RORX); a hybrid that keeps planes
+ * 0, 1 in general registers and planes 2, 3, 4 one lane per xmm register (AVX-512VL) -- one chosen per process by the CPU's features.
+ * Runs every available build on nblocks pseudo-random rate blocks: 0 = all states equal the baseline build's, 1 = one differs. */
 int zk_transcript_selftest(size_t nblocks);
 
 /* ---- MultiLinearPolynomial (polynomials/src/multilinear_polynomial/evaluation_form.rs) */
