@@ -1209,7 +1209,9 @@ __global__ void __launch_bounds__(kThreads) k_fold2_tables(Tab4 S, Tab4w D, size
 }
 
 // the same for three variables (eight weights): small tables, one launch for all four
-__global__ void __launch_bounds__(kThreads) k_fold3_tables(Tab4 S, Tab4w D, size_t outlen, W28<3> W) {
+// gather (may be null): the folded tables ALSO go there, table after table (gather[t * outlen + o]) -- the device-mapped pinned buffer
+// when the host takes over after this fold, instead of one more launch (k_gather4)
+__global__ void __launch_bounds__(kThreads) k_fold3_tables(Tab4 S, Tab4w D, size_t outlen, W28<3> W, fq* __restrict__ gather) {
     const fq* __restrict__ src = S.t[blockIdx.y];
     fq* __restrict__ dst = D.t[blockIdx.y];
     const size_t stride = (size_t)gridDim.x * kThreads;
@@ -1219,7 +1221,9 @@ __global__ void __launch_bounds__(kThreads) k_fold3_tables(Tab4 S, Tab4w D, size
         for (int k = 0; k < 20; ++k) a28[k] = 0;
 #pragma unroll
         for (int b = 0; b < 8; ++b) fq28_mac(a28, fq_load(src + (size_t)b * outlen + o), W.w[b]);
-        fq_store(dst + o, fq28_redc(a28));
+        const fq v = fq28_redc(a28);
+        fq_store(dst + o, v);
+        if (gather) fq_store(gather + (size_t)blockIdx.y * outlen + o, v);
     }
 }
 
@@ -1573,7 +1577,7 @@ void launch_fold3_tables(const void* const s[4], void* const d[4], size_t outlen
                                (const u32*)wbuf, 3, 0, (fq*)partials);
     }
 }
-void launch_fold3_tables_small(const void* const s[4], void* const d[4], size_t outlen, const uint32_t* w28, hipStream_t st) {
+void launch_fold3_tables_small(const void* const s[4], void* const d[4], size_t outlen, const uint32_t* w28, void* gather, hipStream_t st) {
     Tab4 S;
     Tab4w D;
     for (int k = 0; k < 4; ++k) { S.t[k] = (const fq*)s[k]; D.t[k] = (fq*)d[k]; }
@@ -1584,7 +1588,7 @@ void launch_fold3_tables_small(const void* const s[4], void* const d[4], size_t 
     if (gx < 1) gx = 1;
     if (gx > (size_t)kMaxBlocks) gx = kMaxBlocks;
     g_forms |= kFormFold3Reg;
-    hipLaunchKernelGGL(k_fold3_tables, dim3((unsigned)gx, 4), dim3(kThreads), 0, st, S, D, outlen, W);
+    hipLaunchKernelGGL(k_fold3_tables, dim3((unsigned)gx, 4), dim3(kThreads), 0, st, S, D, outlen, W, (fq*)gather);
 }
 void launch_gather4(const void* const t[4], size_t n, void* out, hipStream_t st) {
     Tab4 T;

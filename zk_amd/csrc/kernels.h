@@ -118,7 +118,7 @@ void launch_cross64(const void* const t[4], size_t q, int ring, void* partials, 
 void launch_fold3_tables(const void* const s[4], void* const d[4], size_t outlen, const uint64_t* r3, const uint64_t two24[4], void* wbuf,
                          void* partials, hipStream_t st, const DmaGates& gates = DmaGates());
 // the three-variable fold of all four tables in ONE launch with the eight eq weights as kernel arguments (w28: 8 x 10 limbs): any outlen >= 1
-void launch_fold3_tables_small(const void* const s[4], void* const d[4], size_t outlen, const uint32_t* w28, hipStream_t st);
+void launch_fold3_tables_small(const void* const s[4], void* const d[4], size_t outlen, const uint32_t* w28, void* gather, hipStream_t st);
 // launch_fold2_tables followed by launch_sum9 on its result, as one kernel + the second stage (small, cache-resident tables; outlen >= 4)
 // Returns 0 when out holds the nine sums.  With at most host_groups_max workgroups in the launch (out must then hold 9 elements per
 // workgroup, normally pinned host memory) there is no second stage: returns G = the number of workgroups, out[g * 9 + s] = workgroup

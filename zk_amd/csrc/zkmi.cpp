@@ -941,6 +941,7 @@ static int prove_sum2x2_pairs(zk_ctx* c, const void* const tables[4], size_t len
     // nine U sums of k_sum9_lazy (kU) -- the last two are finished here on the host instead of by one more small launch
     constexpr int kU = -1;
     int sums_kind = 0;
+    bool gathered = false; // the last fold has left the four small tables in the pinned buffer already
     bool have27 = false; // the pinned buffer holds k_fold_sum27's 27 sums (or sums_kind workgroups' shares of them): three rounds
     auto launch_sums = [&](const void* const t[4], size_t n) -> int {
         ProfScope ps(c, ZK_K_SUM9, (uint64_t)n * 32 * 4);
@@ -1051,7 +1052,9 @@ static int prove_sum2x2_pairs(zk_ctx* c, const void* const tables[4], size_t len
                 if (K == 3 && (outlen < kFold3SmallBelow || outlen % 64)) {
                     uint32_t w28[8 * 10]; // small tables: one launch, weights as kernel arguments
                     eq_weights28(rs, 3, w28);
-                    zkk::launch_fold3_tables_small(cur, dst, outlen, w28, c->stream);
+                    // the host takes over after this fold: the folded tables go to the pinned buffer too (no k_gather4 launch)
+                    gathered = outlen <= kHostTail;
+                    zkk::launch_fold3_tables_small(cur, dst, outlen, w28, gathered ? c->sums_host_dev : nullptr, c->stream);
                 } else if (K == 3) {
                     zkk::launch_fold3_tables(cur, dst, outlen, rs, c->two24, c->wide_w, c->partials, c->stream, c->gates);
                 } else {
@@ -1068,7 +1071,7 @@ static int prove_sum2x2_pairs(zk_ctx* c, const void* const tables[4], size_t len
     }
     HIPCHK(c, hipGetLastError());
     // the rest (<= kHostTail entries per table, at least 2 variables' worth unless len was tiny) on the host
-    zkk::launch_gather4(cur, curlen, c->sums_host_dev, c->stream);
+    if (!gathered) zkk::launch_gather4(cur, curlen, c->sums_host_dev, c->stream);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));
     std::vector<Fq> T(4 * curlen);
