@@ -101,8 +101,9 @@ class Keccak256 {
   private:
     static inline uint64_t rotl(uint64_t x, int n) { return (x << n) | (x >> (64 - n)); }
 
-    // Whole blocks.  The round function is the same source compiled twice: for the baseline x86-64 ISA and with BMI1/BMI2 (ANDN for
-    // chi's ~a & b, RORX for non-destructive rotations: fewer instructions and moves per round), chosen once per process.
+    // Whole blocks, in the build this CPU runs fastest (chosen once per process): the scalar round function compiled for the baseline
+    // x86-64 ISA and again with BMI1/BMI2 (ANDN for chi's ~a & b, RORX for non-destructive rotations: fewer instructions and moves
+    // per round), or the hybrid scalar + vector form below.
     static void absorb_blocks(uint64_t* s, const uint8_t* data, size_t nblocks) {
 #if defined(__x86_64__)
         static const int form = best_form();
