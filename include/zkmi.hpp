@@ -202,6 +202,19 @@ struct SumcheckProver {
         pts.resize(n);
         return {SumCheckProof{initial_claim_sum, detail::unflatten(coeffs, n, 3)}, pts};
     }
+    // The same for SumPolynomial[Product[f, g], Product[h, ones]] -- the relation f g + h of a GKR phase (gkr/src/prover.rs:55-147) -- without
+    // the table of ones: same proof bytes, the constant factor is never read (zk_sumcheck_prove_prod_plus_linear).
+    static std::pair<SumCheckProof, std::vector<Fq>> generate_proof_product_plus_linear(const Fq& initial_claim_sum, const MultiLinearPolynomial& f,
+                                                                                       const MultiLinearPolynomial& g, const MultiLinearPolynomial& h,
+                                                                                       Transcript& transcript) {
+        zk_mle* t[3] = {f.get(), g.get(), h.get()};
+        const size_t n = f.number_of_variables();
+        std::vector<Fq> coeffs(3 * n + 1), pts(n + 1);
+        auto& c = f.ctx();
+        c->check(zk_sumcheck_prove_prod_plus_linear(c->get(), t, initial_claim_sum.l, transcript.get(), coeffs[0].l, pts[0].l));
+        pts.resize(n);
+        return {SumCheckProof{initial_claim_sum, detail::unflatten(coeffs, n, 3)}, pts};
+    }
 };
 
 // sumcheck::verifier::SumcheckVerifier (sumcheck/src/verifier.rs:9-95)

@@ -110,6 +110,22 @@ static void test_partial_sumcheck_pass() { // sumcheck_protocol.rs:85-111
     CHECK(panics_with(ZK_E_DEGREE, [&] { SumcheckProver::generate_proof_for_partial_verify(Fq(6), one, t3); }));
     CHECK(panics_with(ZK_E_LEN_MISMATCH, [&] { ProductPolynomial({MLE(e1), MLE(F({1, 2}))}); })); // product_polynomial.rs:15-19
 }
+static void test_product_plus_linear_equals_the_four_table_form() { // the GKR phase relation f g + h (gkr/src/prover.rs:55-147: Product[h, ones])
+    std::vector<Fq> fv, gv, hv, ones;
+    for (unsigned i = 0; i < 256; ++i) { // 256 entries: above the host tail, so the device kernels of the product-plus-linear form run
+        fv.push_back(Fq(3 * i + 1)); gv.push_back(Fq(i * i + 7)); hv.push_back(Fq(1000003u * i + 11)); ones.push_back(Fq(1));
+    }
+    SumPolynomial four({ProductPolynomial({MLE(fv), MLE(gv)}), ProductPolynomial({MLE(hv), MLE(ones)})});
+    Transcript t4, t3;
+    auto [p4, pts4] = SumcheckProver::generate_proof_for_partial_verify(Fq(5), four, t4);
+    auto [p3, pts3] = SumcheckProver::generate_proof_product_plus_linear(Fq(5), MLE(fv), MLE(gv), MLE(hv), t3);
+    CHECK(p4.round_polys.size() == 8 && p3.round_polys.size() == 8 && pts3.size() == 8);
+    for (size_t k = 0; k < 8; ++k) {
+        CHECK(pts3[k] == pts4[k]);
+        for (size_t j = 0; j < 3; ++j) CHECK(p3.round_polys[k].coefficients[j] == p4.round_polys[k].coefficients[j]);
+    }
+    CHECK(t3.sample_challenge() == t4.sample_challenge()); // the transcripts end in the same state
+}
 static void test_circuit() { // circuit.rs:159-202
     Circuit c({{Gate(0, 1, Operation::Add), Gate(2, 3, Operation::Mul)}, {Gate(0, 1, Operation::Add)}});
     auto ev = c.evaluate_at_input(F({1, 2, 3, 4}));
@@ -143,6 +159,7 @@ int main() {
         {"test_full_sumcheck_pass", test_full_sumcheck_pass},
         {"test_full_sumcheck_fail", test_full_sumcheck_fail},
         {"test_partial_sumcheck_pass", test_partial_sumcheck_pass},
+        {"test_product_plus_linear_equals_the_four_table_form", test_product_plus_linear_equals_the_four_table_form},
         {"test_circuit", test_circuit},
         {"test_gkr_sum_check", test_gkr_sum_check},
     };
