@@ -65,7 +65,6 @@ def parse(argv=None):
     ap.add_argument("--deg2-mfma-from", type=int, default=None, help="degree-2 prover: nine sums on the matrix cores from 2^k quarter-entries (64 = never)")
     ap.add_argument("--deg2-triple-from", type=int, default=None, help="degree-2 prover: three rounds per pass on tables of >= 2^k entries (64 = never)")
     ap.add_argument("--deg2-small-triple", type=int, default=None, help="degree-2 prover: three rounds per pass (fold + 27 sums in one kernel) for folded tables below 2^k entries (0 = never)")
-    ap.add_argument("--sums-inflight", type=int, default=None, help="entries in flight per lane of the register-load block sums (0, 2, 4, 8)")
     ap.add_argument("--dma-gates", type=int, nargs=3, default=None, metavar=("SUMS_FROM", "WIDE_STREAM_FROM", "FOLD2_FROM"),
                     help="size thresholds (log2 entries) of the LDS-DMA block sums, the streaming stores of the wide fold and the LDS-DMA two-variable fold (library defaults 27 22 22)")
     ap.add_argument("--deg2-first-triple", type=int, nargs=2, default=None, metavar=("BELOW", "LINEAR_BELOW"),
@@ -372,8 +371,6 @@ def apply_knobs(args, ctx):
         ctx.set_deg2_fused(args.deg2_fused_below)
     if args.deg2_small_triple is not None:
         ctx.set_deg2_small_triple(args.deg2_small_triple)
-    if args.sums_inflight is not None:
-        ctx.set_sums_inflight(args.sums_inflight)
     if args.dma_gates is not None:
         ctx.set_dma_gates(*args.dma_gates)
     if args.deg2_first_triple is not None:

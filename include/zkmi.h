@@ -387,10 +387,6 @@ int zk_ctx_set_deg2_lazy_sums(zk_ctx *ctx, int from_log);
  * m = 2 LDS-DMA passes from 2^fold2_from_log outputs per table (default 22).  The parity tests lower them so that the
  * kernels the benchmark numbers come from run on oracle-sized tables.  Proof bytes do not depend on any of it. */
 int zk_ctx_set_dma_gates(zk_ctx *ctx, int sums_from_log, int wide_stream_from_log, int fold2_from_log);
-/* Block sums below the LDS-DMA gate: entries (2, 4 or 8) kept in flight per lane by the register-load kernel, which then adds
- * them as plain 256-bit integers and reduces once per lane; 0 = the two-in-flight kernel with a modular addition per entry.
- * Proof bytes do not depend on it. */
-int zk_ctx_set_sums_inflight(zk_ctx *ctx, int entries);
 /* Wide fold passes with at least 2^from_log outputs (default 15; 64 = never) run their contraction on the matrix cores
  * (v_mfma_i32_16x16x64_i8 over the raw table bytes and signed radix-256 digits of the eq weights) instead
  * of the vector ALU; workgroups_per_cu (1..8) sizes its grid, depth (2..4) is the number of steps (4 KiB of table rows per

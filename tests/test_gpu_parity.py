@@ -457,36 +457,6 @@ def test_dma_gate_arguments():
     assert c.forms_used() == {"sums_reg"}
 
 
-@pytest.mark.parametrize("inflight", [2, 4, 8])
-def test_block_sums_unreduced_accumulator_vs_oracle(inflight):
-    """k_block_sums_lazy (U entries in flight, nine-word plain accumulator): full proofs against the oracle on small tables, and the
-    carry word on tables of p - 1 whose lanes add up to 16 entries (more than 2^256) against the closed form n/2 * (p - 1) mod p"""
-    c = zk_amd.Context(0)
-    c.set_dma_gates(64, 22, 22)
-    with pytest.raises(zk_amd.ZkError):
-        c.set_sums_inflight(3)
-    c.set_sums_inflight(inflight)
-    for log_n in (9, 14, 17):
-        table = O.gen_table(SEED + 900 + log_n, 0, 1 << log_n)
-        c.forms_used()
-        proof, ch = zk_amd.SumcheckProver.generate_sumcheck_proof(MLE(table, ctx=c), return_challenges=True)
-        assert "sums_reg" in c.forms_used()
-        oclaim, ocoeffs, och = O.sumcheck_prove(table)
-        assert list(proof.initial_claim_sum) == list(oclaim) and np.array_equal(proof.round_polys, ocoeffs) and np.array_equal(ch, och)
-    ref = zk_amd.Context(0)
-    ref.set_dma_gates(64, 22, 22)
-    for log_n in (20, 21, 22, 23):
-        n = 1 << log_n
-        t = np.empty((n, 4), dtype=np.uint64)
-        t[:] = np.array([(P - 1) >> (64 * k) & (2**64 - 1) for k in range(4)], dtype=np.uint64)
-        want = (P - n // 2) % P
-        got = MLE(t, ctx=c).round_sums()
-        assert np.array_equal(got, MLE(t, ctx=ref).round_sums()), log_n
-        for e in got:
-            assert sum(int(e[k]) << (64 * k) for k in range(4)) == want, log_n
-        del t
-
-
 # ---- compute_quotient_remainder / minus (evaluation_form.rs:260-301; the division step of kzg/src/multilinear/prover.rs:59-96)
 @pytest.mark.parametrize("log_n", [1, 2, 3, 6, 11, 16])
 def test_quotient_remainder_every_variable_vs_oracle(ctx, log_n):

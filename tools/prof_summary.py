@@ -62,7 +62,7 @@ def pmc(d):
 def traffic_dict(rd_dir, wr_dir, log_n):
     """HBM bytes per launch of the bench kernels from a FETCH_SIZE pass and a WRITE_SIZE pass (what bench.py reports as
     roofline.traffic: from its own counter passes when rocprofv3 is there, else from the committed file of the same command)."""
-    names = {"k_multifold_lazy": "multifold", "k_multifold": "multifold", "k_multifold_roll": "multifold", "k_multifold_wide": "multifold_wide", "k_multifold_wide_lds": "multifold_wide", "k_multifold_wide_dma": "multifold_wide", "k_multifold_wide_mfma": "multifold_wide", "k_block_sums_dma": "block_sums", "k_multifold_coop": "multifold_tail", "k_block_sums": "block_sums", "k_block_sums_lazy": "block_sums",
+    names = {"k_multifold_lazy": "multifold", "k_multifold": "multifold", "k_multifold_roll": "multifold", "k_multifold_wide": "multifold_wide", "k_multifold_wide_lds": "multifold_wide", "k_multifold_wide_dma": "multifold_wide", "k_multifold_wide_mfma": "multifold_wide", "k_block_sums_dma": "block_sums", "k_multifold_coop": "multifold_tail", "k_block_sums": "block_sums",
              "k_sum9": "sum9", "k_sum9_lazy": "sum9", "k_sum9_mfma": "sum9", "k_sum16_mfma": "sum9", "k_cross64_mfma": "sum9", "k_fold2_tables": "fold2x4_sum9", "k_fold2_tables_dma": "fold2x4_sum9",
              "k_fold3_tables_dma": "fold2x4_sum9", "k_fold3_tables": "fold2x4_sum9", "k_fold2_sum9": "fold2x4_sum9", "k_fold_sum27": "fold2x4_sum9", "k_fold3_cross64": "fold2x4_sum9",
              "k_fold3_cross64_mfma": "fold2x4_sum9", "k_eval3": "eval3", "k_fold4_eval3": "fold4_eval3"}

@@ -96,10 +96,6 @@ class Context:
         matrix cores + one three-variable fold); 64 = never.  ring = LDS tiles of the sweep (3 or 4).  Defaults = the library's (kernels.h DmaGates)."""
         check(lib().zk_ctx_set_deg2_triple(self.h, from_log, ring))
 
-    def set_sums_inflight(self, entries: int = 0):
-        """Entries in flight per lane of the register-load block sums (0, 2, 4, 8); zk_ctx_set_sums_inflight."""
-        check(lib().zk_ctx_set_sums_inflight(self.h, entries))
-
     def set_dma_gates(self, sums_from_log: int = 27, wide_stream_from_log: int = 22, fold2_from_log: int = 22):
         """Size thresholds (log2 entries, 64 = never) of the LDS-DMA forms of the big passes.  Proof bytes do not depend on it."""
         check(lib().zk_ctx_set_dma_gates(self.h, sums_from_log, wide_stream_from_log, fold2_from_log))

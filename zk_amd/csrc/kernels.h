@@ -47,7 +47,6 @@ extern thread_local unsigned g_forms;
 // Size thresholds of the LDS-DMA forms (log2 of entries; defaults = the measured break-even points)
 struct DmaGates {
     int sums_from_log = 27;        // block sums by LDS-DMA from tables of 2^k entries
-    int sums_reg_inflight = 0;     // register-load block sums: 2, 4 or 8 entries in flight per lane with an unreduced accumulator (k_block_sums_lazy); 0 = k_block_sums
     int wide_stream_from_log = 22; // wide fold: streaming (nontemporal) stores from 2^k outputs
     int fold2_from_log = 22;       // degree-2 two-variable fold by LDS-DMA from 2^k outputs per table
     int wide_mfma_from_log = 15;   // wide fold on the matrix cores (k_multifold_wide_mfma) from 2^k outputs; 64 = never

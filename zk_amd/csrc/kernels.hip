@@ -37,43 +37,6 @@ thread_local unsigned g_forms = 0;
 // grid-strides inside it, so every thread carries ONE accumulator whatever the batch size.
 
 // partials[w] = this workgroup's share of the sum of block w / gpb of T (L entries)
-// The same sums with U entries (2 U 16-byte loads) in flight per lane and trip and an UNREDUCED accumulator: entries are added as
-// plain 256-bit integers into nine words (8 add-with-carry + the carry word; 2^32 entries per lane before it could overflow) and
-// reduced once at the end: lo mod p + hi * 2^256 mod p (fq_mul(hi, R^2) = hi * R).  The sums are the same field elements.
-template <int U>
-__global__ void __launch_bounds__(kThreads) k_block_sums_lazy(const fq* __restrict__ T, size_t L, int log_ob, fq* __restrict__ partials) {
-    const unsigned gpb = gridDim.x >> log_ob;
-    const unsigned c = blockIdx.x / gpb, wl = blockIdx.x % gpb;
-    const size_t Lb = L >> log_ob;
-    const fq* __restrict__ base = T + (size_t)c * Lb;
-    const size_t stride = (size_t)gpb * kThreads;
-    u32 a[9];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) a[k] = 0;
-    auto add = [&](const fq& x) {
-        u32 cy = 0;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) a[k] = __builtin_addc(a[k], x.v[k], cy, &cy);
-        a[8] += cy;
-    };
-    size_t i = (size_t)wl * kThreads + threadIdx.x;
-    for (; i + (U - 1) * stride < Lb; i += U * stride) {
-        fq x[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) x[u] = fq_load_stream(base + i + u * stride);
-#pragma unroll
-        for (int u = 0; u < U; ++u) add(x[u]);
-    }
-    for (; i < Lb; i += stride) add(fq_load_stream(base + i));
-    fq lo, hi = fq_zero();
-#pragma unroll
-    for (int k = 0; k < 8; ++k) lo.v[k] = a[k];
-    hi.v[0] = a[8];
-    const fq r2 = {FQ_R2_LIMBS};
-    fq acc[1] = {fq_add(fq_reduce_256(lo), fq_mul(hi, r2))};
-    block_sum_store<1>(acc, partials);
-}
-
 __global__ void __launch_bounds__(kThreads) k_block_sums(const fq* __restrict__ T, size_t L, int log_ob, fq* __restrict__ partials) {
     const unsigned gpb = gridDim.x >> log_ob;
     const unsigned c = blockIdx.x / gpb, wl = blockIdx.x % gpb;
@@ -802,14 +765,7 @@ int launch_block_sums(const void* T, size_t L, int log_ob, void* partials, void*
     }
     int g = grid_blocks(L >> log_ob, log_ob);
     g_forms |= kFormSumsReg;
-    if (gates.sums_reg_inflight == 4)
-        hipLaunchKernelGGL(k_block_sums_lazy<4>, dim3(g), dim3(kThreads), 0, st, (const fq*)T, L, log_ob, (fq*)sums_target(g, log_ob, partials, out));
-    else if (gates.sums_reg_inflight == 8)
-        hipLaunchKernelGGL(k_block_sums_lazy<8>, dim3(g), dim3(kThreads), 0, st, (const fq*)T, L, log_ob, (fq*)sums_target(g, log_ob, partials, out));
-    else if (gates.sums_reg_inflight == 2)
-        hipLaunchKernelGGL(k_block_sums_lazy<2>, dim3(g), dim3(kThreads), 0, st, (const fq*)T, L, log_ob, (fq*)sums_target(g, log_ob, partials, out));
-    else
-        hipLaunchKernelGGL(k_block_sums, dim3(g), dim3(kThreads), 0, st, (const fq*)T, L, log_ob, (fq*)sums_target(g, log_ob, partials, out));
+    hipLaunchKernelGGL(k_block_sums, dim3(g), dim3(kThreads), 0, st, (const fq*)T, L, log_ob, (fq*)sums_target(g, log_ob, partials, out));
     reduce_groups_unless_single(g, log_ob, partials, out, st);
     return g;
 }

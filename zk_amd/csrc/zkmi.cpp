@@ -1468,11 +1468,6 @@ int zk_ctx_set_dma_gates(zk_ctx* c, int sums_from_log, int wide_stream_from_log,
     c->gates.fold2_from_log = fold2_from_log;
     return ZK_OK;
 }
-int zk_ctx_set_sums_inflight(zk_ctx* c, int entries) {
-    if (!c || (entries != 0 && entries != 2 && entries != 4 && entries != 8)) return ZK_E_ARG;
-    c->gates.sums_reg_inflight = entries;
-    return ZK_OK;
-}
 int zk_ctx_set_wide_mfma(zk_ctx* c, int from_log, int workgroups_per_cu, int depth) {
     if (!c || from_log < 0 || from_log > 64 || workgroups_per_cu < 1 || workgroups_per_cu > 8 || depth < 2 || depth > 4) return ZK_E_ARG;
     c->gates.wide_mfma_from_log = from_log;
