@@ -65,6 +65,7 @@ def parse(argv=None):
     ap.add_argument("--deg2-mfma-from", type=int, default=None, help="degree-2 prover: nine sums on the matrix cores from 2^k quarter-entries (64 = never)")
     ap.add_argument("--deg2-triple-from", type=int, default=None, help="degree-2 prover: three rounds per pass on tables of >= 2^k entries (64 = never)")
     ap.add_argument("--deg2-small-triple", type=int, default=None, help="degree-2 prover: three rounds per pass (fold + 27 sums in one kernel) for folded tables below 2^k entries (0 = never)")
+    ap.add_argument("--deg2-raw-cross", type=int, default=None, help="1 (library default): the three-round sweeps leave raw digits for the second stage; 0: field elements per workgroup")
     ap.add_argument("--dma-gates", type=int, nargs=3, default=None, metavar=("SUMS_FROM", "WIDE_STREAM_FROM", "FOLD2_FROM"),
                     help="size thresholds (log2 entries) of the LDS-DMA block sums, the streaming stores of the wide fold and the LDS-DMA two-variable fold (library defaults 27 22 22)")
     ap.add_argument("--deg2-first-triple", type=int, nargs=2, default=None, metavar=("BELOW", "LINEAR_BELOW"),
@@ -371,6 +372,8 @@ def apply_knobs(args, ctx):
         ctx.set_deg2_fused(args.deg2_fused_below)
     if args.deg2_small_triple is not None:
         ctx.set_deg2_small_triple(args.deg2_small_triple)
+    if args.deg2_raw_cross is not None:
+        ctx.set_deg2_raw_cross(bool(args.deg2_raw_cross))
     if args.dma_gates is not None:
         ctx.set_dma_gates(*args.dma_gates)
     if args.deg2_first_triple is not None:

@@ -418,6 +418,11 @@ int zk_ctx_set_deg2_fold3_fused(zk_ctx *ctx, int dma_slots);
  * (prover.rs:131-139, twice) and the nine sums of its result (the next two rounds' prover.rs:89-107) are one kernel -- GKR layer
  * tables are cache-resident and a pass is bound by launches and per-lane chains, not by bytes.  Proof bytes do not depend on it. */
 int zk_ctx_set_deg2_fused(zk_ctx *ctx, int below_log);
+/* Degree-2 prover, three-round sweeps (k_cross64_mfma, k_fold3_cross64_mfma): on (default) = every workgroup leaves its 64 cross sums
+ * as signed integer digits in a context-owned device buffer (64 KiB per workgroup pair, made on first use, grow-only) and the second
+ * stage adds the digits over the workgroups before the one field product per digit; off = every workgroup forms its field elements
+ * itself (the form of rounds 2 and 3a).  Integer addition is exact: proof bytes do not depend on it. */
+int zk_ctx_set_deg2_raw_cross(zk_ctx *ctx, int on);
 /* Degree-2 prover, THREE rounds per pass on small tables: while the folded tables have fewer than 2^below_log entries (default 20; 0 = never) a
  * pass folds the variables of the rounds just run (prover.rs:131-139) and forms the 27 sums that determine the next three round
  * polynomials (prover.rs:89-107, three times) in one kernel -- a pass on a cache-resident table costs its host round trip, so it

@@ -174,8 +174,11 @@ def test_sum2x2_2pow24_both_nine_sum_kernels_agree():
     passes) give the same proof bytes at full size."""
     proofs = []
     # (lazy_from, mfma_from, triple_from, fused_below); the last: the defaults (three rounds per pass from 2^21, fused small passes)
-    for lazy_from, mfma_from, triple_from, fused_below in ((20, 64, 64, 0), (-1, 64, 64, 0), (20, 22, 64, 0), (18, 22, 21, 20)):
+    # the fifth: the defaults with every workgroup of the three-round sweeps forming its own field elements (no raw digits)
+    for lazy_from, mfma_from, triple_from, fused_below, raw in ((20, 64, 64, 0, True), (-1, 64, 64, 0, True), (20, 22, 64, 0, True), (18, 22, 21, 20, True),
+                                                                  (18, 22, 21, 20, False)):
         ctx = zk_amd.Context(0)
+        ctx.set_deg2_raw_cross(raw)
         ctx.set_deg2_lazy_sums(lazy_from)
         ctx.set_deg2_mfma_sums(mfma_from)
         ctx.set_deg2_triple(triple_from, 4)

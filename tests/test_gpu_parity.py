@@ -798,15 +798,17 @@ def test_sum2x2_three_rounds_per_pass_vs_oracle(log_n, ring):
         assert np.array_equal(t.get_evaluation_points(), src)      # the factor tables are left unmodified
 
 
+@pytest.mark.parametrize("raw", [True, False])
 @pytest.mark.parametrize("slots", [3, 4, 5, 8])
 @pytest.mark.parametrize("log_n", [12, 13, 15, 16, 18])
-def test_sum2x2_fold_fused_with_next_cross_sums_vs_oracle(log_n, slots):
+def test_sum2x2_fold_fused_with_next_cross_sums_vs_oracle(log_n, slots, raw):
     """k_fold3_cross64 (slots 3..5) / k_fold3_cross64_mfma (slots = 8: the fold on the matrix cores too): the three-variable fold and
     the next level's cross sums in one sweep (tables of >= 2^12 entries have a successor pass of whole 64-entry eighths).  Same proof
-    bytes as the oracle."""
+    bytes as the oracle.  raw: the sweeps leave integer digits for the second stage (default) / field elements per workgroup."""
     c = zk_amd.Context(0)
     c.set_deg2_triple(0, 4)
     c.set_deg2_fold3_fused(slots)
+    c.set_deg2_raw_cross(raw)
     n = 1 << log_n
     tabs = [O.gen_table(SEED + 340 + k, 0, n) for k in range(4)]
     m = [MLE(t, ctx=c) for t in tabs]
@@ -823,10 +825,12 @@ def test_sum2x2_fold_fused_with_next_cross_sums_vs_oracle(log_n, slots):
         assert np.array_equal(t.get_evaluation_points(), src)
 
 
+@pytest.mark.parametrize("raw", [True, False])
 @pytest.mark.parametrize("fill", ["p-1", "zero", "byteff", "mixed"])
-def test_sum2x2_three_rounds_per_pass_extreme_bytes(fill):
+def test_sum2x2_three_rounds_per_pass_extreme_bytes(fill, raw):
     c = zk_amd.Context(0)
     c.set_deg2_triple(0, 3)
+    c.set_deg2_raw_cross(raw)
     n = 1 << 12
 
     def const_table(raw):

@@ -129,6 +129,7 @@ SYMBOLS = [
     ("zk_mle_count_noncanonical", C.c_int, [_VP, C.POINTER(C.c_uint64)]),
     ("zk_ctx_set_gkr_strict_claims", C.c_int, [_VP, C.c_int]),
     ("zk_ctx_set_dma_gates", C.c_int, [_VP, C.c_int, C.c_int, C.c_int]),
+    ("zk_ctx_set_deg2_raw_cross", C.c_int, [_VP, C.c_int]),
     ("zk_ctx_set_wide_mfma", C.c_int, [_VP, C.c_int, C.c_int, C.c_int]),
     ("zk_ctx_forms_used", C.c_uint, [_VP, C.c_int]),
     ("zk_prof_enable", C.c_int, [_VP, C.c_int]),

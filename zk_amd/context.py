@@ -96,6 +96,10 @@ class Context:
         matrix cores + one three-variable fold); 64 = never.  ring = LDS tiles of the sweep (3 or 4).  Defaults = the library's (kernels.h DmaGates)."""
         check(lib().zk_ctx_set_deg2_triple(self.h, from_log, ring))
 
+    def set_deg2_raw_cross(self, on: bool = True):
+        """Three-round sweeps leave raw integer digits for the second stage (default) or form field elements per workgroup; zk_ctx_set_deg2_raw_cross."""
+        check(lib().zk_ctx_set_deg2_raw_cross(self.h, 1 if on else 0))
+
     def set_dma_gates(self, sums_from_log: int = 27, wide_stream_from_log: int = 22, fold2_from_log: int = 22):
         """Size thresholds (log2 entries, 64 = never) of the LDS-DMA forms of the big passes.  Proof bytes do not depend on it."""
         check(lib().zk_ctx_set_dma_gates(self.h, sums_from_log, wide_stream_from_log, fold2_from_log))

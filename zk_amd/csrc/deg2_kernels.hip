@@ -443,7 +443,7 @@ __global__ void __launch_bounds__(64) k_sum9_from_p16(const fq* __restrict__ in4
 // the same ring with the matrix and LDS work removed 6.2, two 2-tile workgroups per CU 5.3, default instead of nt load policy 5.6.
 // partials: [(term * gridDim.x + bx) * 80 + ...]: 64 values P_signed[e][e'] * 2^-256 (index 8 e + e'), then A_e (8), then B_e' (8).
 template <int R>
-__global__ void __launch_bounds__(512) k_cross64_mfma(Tab4 T, size_t q, fq* __restrict__ partials) {
+__global__ void __launch_bounds__(512) k_cross64_mfma(Tab4 T, size_t q, fq* __restrict__ partials, long long* __restrict__ raw) {
     constexpr int NE = 8;
     __shared__ u32x4 sh[R][2 * NE][128];
     const int term = blockIdx.y, lane = threadIdx.x & 63;
@@ -566,6 +566,10 @@ __global__ void __launch_bounds__(512) k_cross64_mfma(Tab4 T, size_t q, fq* __re
             d += (j >= 0 && j < 32) ? v : 0;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (raw) { // the digits themselves: k_reduce_cross_raw adds them over the workgroups as integers and multiplies once
+            raw[((((size_t)term * gridDim.x + blockIdx.x) * (NE * NE)) + (size_t)(NE * (2 * wa + (e >> 2)) + 4 * wh + (e & 3))) * 64 + lane] = d;
+            continue;
+        }
         const bool neg = d < 0;
         const unsigned long long ad = (unsigned long long)(neg ? -d : d);
         fq x = fq_zero();
@@ -857,7 +861,8 @@ __device__ __forceinline__ fq mfma_fold_finish(const v4i (&fa)[4][4], const fq& 
 
 template <bool BIG, int NP>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
-k_fold3_cross64_mfma(Tab4 S, Tab4w Dst, size_t outlen, const u32x4* __restrict__ wtiles, fq kfix, fq* __restrict__ partials) {
+k_fold3_cross64_mfma(Tab4 S, Tab4w Dst, size_t outlen, const u32x4* __restrict__ wtiles, fq kfix, fq* __restrict__ partials,
+                     long long* __restrict__ raw) {
     constexpr int NE = 8;
     __shared__ u32x4 tile[2 * NE][128];
     __shared__ u32x4 wl[4][4][64];
@@ -1122,6 +1127,10 @@ k_fold3_cross64_mfma(Tab4 S, Tab4w Dst, size_t outlen, const u32x4* __restrict__
             d += (j >= 0 && j < 32) ? v : 0;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (raw) { // as in k_cross64_mfma
+            raw[((((size_t)term * gridDim.x + blockIdx.x) * (NE * NE)) + (size_t)(NE * (4 * fi + (e >> 2)) + 4 * gi + (e & 3))) * 64 + lane] = d;
+            continue;
+        }
         const bool neg = d < 0;
         const unsigned long long ad = (unsigned long long)(neg ? -d : d);
         fq xx = fq_zero();
@@ -1148,6 +1157,42 @@ __global__ void __launch_bounds__(kThreads) k_reduce_cross(const fq* __restrict_
     fq acc[1] = {fq_zero()};
     for (int b = threadIdx.x; b < gx; b += kThreads) acc[0] = fq_add(acc[0], fq_load(partials + ((size_t)term * gx + b) * nv + v));
     block_sum_store<1>(acc, red);
+}
+// The same second stage when the sweeps leave the 64 cross sums of a workgroup as RAW digits: raw[((term * gx + b) * 64 + v) * 64 + k] =
+// the signed integer D_k of  P_signed = sum_k D_k 256^k  (k < 63; |D_k| < 2^37 per workgroup).  Integers add exactly, so the digits
+// are summed over the workgroups first and ONE product per digit, 256^k 2^-256 mod p, replaces one per digit and workgroup in the
+// sweeps' epilogues.  Values 64..79 (the plain sums) as in k_reduce_cross.
+__global__ void __launch_bounds__(kThreads) k_reduce_cross_raw(const long long* __restrict__ raw, const fq* __restrict__ partials, int gx,
+                                                               fq* __restrict__ red) {
+    const int term = blockIdx.x / 80, v = blockIdx.x % 80;
+    if (v >= 64) { // uniform per block
+        fq acc[1] = {fq_zero()};
+        for (int b = threadIdx.x; b < gx; b += kThreads) acc[0] = fq_add(acc[0], fq_load(partials + ((size_t)term * gx + b) * 80 + v));
+        block_sum_store<1>(acc, red);
+        return;
+    }
+    __shared__ long long sh[kThreads / 64][64];
+    const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    long long s = 0;
+    for (int b = slice; b < gx; b += kThreads / 64) s += raw[(((size_t)term * gx + b) * 64 + v) * 64 + lane];
+    sh[slice][lane] = s;
+    __syncthreads();
+    if (slice != 0) return;
+    long long d = 0;
+#pragma unroll
+    for (int k = 0; k < kThreads / 64; ++k) d += sh[k][lane];
+    fq wk;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) wk.v[k] = kPow256ModP[lane < 63 ? lane : 0][k];
+    const bool neg = d < 0;
+    const unsigned long long ad = (unsigned long long)(neg ? -d : d);
+    fq x = fq_zero();
+    x.v[0] = (u32)ad;
+    x.v[1] = (u32)(ad >> 32);
+    fq prod = fq_mul(x, wk);
+    if (neg) prod = fq_sub(fq_zero(), prod);
+    const fq mine = fq_wave_sum(prod);
+    if (lane == 0) fq_store(red + blockIdx.x, mine);
 }
 // out[term * 64 + 8 e + e'] = P[e][e'] = P_signed + 128 c1 (A_e + B_e') 2^-256 - 2^14 c1^2 N 2^-256 (see k_sum16_mfma); one block of 128
 __global__ void __launch_bounds__(128) k_cross64_fix(const fq* __restrict__ red, fq qn, fq* __restrict__ out) {
@@ -1503,35 +1548,38 @@ int launch_sum9(const void* const t[4], size_t q, const uint64_t fix24[4], int l
 // a workgroup's i32 accumulators take 2^16 quarter-indices: |byte - 128| <= 128, so a product is <= 2^14 and 2^16 of them stay below
 // 2^31 with a factor of two to spare (2^17 all-zero entries would reach exactly 2^31)
 bool cross64_fits(size_t q) { return q >= 64 && q % 64 == 0 && q <= ((size_t)kMaxBlocks9 << 16); }
-void launch_cross64(const void* const t[4], size_t q, int ring, void* partials, void* out, hipStream_t st) {
-    Tab4 T;
-    for (int k = 0; k < 4; ++k) T.t[k] = (const fq*)t[k];
-    // one workgroup per CU and term half: 128 x 2 persistent workgroups; more only to keep a workgroup's share within the i32
-    // accumulators (2^16 quarter-indices)
+// one workgroup per CU and term half: 128 x 2 persistent workgroups; more only to keep a workgroup's share within the i32
+// accumulators (2^16 quarter-indices)
+static size_t cross64_grid(size_t q) {
     size_t gx = std::min<size_t>(q / 64, 128);
     const size_t need = (q + ((size_t)1 << 16) - 1) >> 16;
-    if (gx < need) gx = need;
+    return gx < need ? need : gx;
+}
+size_t cross64_raw_bytes(size_t q) { return 2 * cross64_grid(q) * 64 * 64 * sizeof(long long); }
+void launch_cross64(const void* const t[4], size_t q, int ring, void* partials, void* raw, void* out, hipStream_t st) {
+    Tab4 T;
+    for (int k = 0; k < 4; ++k) T.t[k] = (const fq*)t[k];
+    const size_t gx = cross64_grid(q);
     fq* red = (fq*)partials + 2 * gx * 80; // 160 reduced values behind the partials (kSum9PartialElems)
     fq qn{};
     qn.v[0] = (u32)q;
     qn.v[1] = (u32)((u64)q >> 32);
     g_forms |= kFormCross64;
-    if (ring == 5) hipLaunchKernelGGL((k_cross64_mfma<5>), dim3((unsigned)gx, 2), dim3(512), 0, st, T, q, (fq*)partials);
-    else if (ring == 4) hipLaunchKernelGGL((k_cross64_mfma<4>), dim3((unsigned)gx, 2), dim3(512), 0, st, T, q, (fq*)partials);
-    else hipLaunchKernelGGL((k_cross64_mfma<3>), dim3((unsigned)gx, 2), dim3(512), 0, st, T, q, (fq*)partials);
-    hipLaunchKernelGGL(k_reduce_cross, dim3(160), dim3(kThreads), 0, st, (const fq*)partials, (int)gx, 80, red);
+    if (ring == 5) hipLaunchKernelGGL((k_cross64_mfma<5>), dim3((unsigned)gx, 2), dim3(512), 0, st, T, q, (fq*)partials, (long long*)raw);
+    else if (ring == 4) hipLaunchKernelGGL((k_cross64_mfma<4>), dim3((unsigned)gx, 2), dim3(512), 0, st, T, q, (fq*)partials, (long long*)raw);
+    else hipLaunchKernelGGL((k_cross64_mfma<3>), dim3((unsigned)gx, 2), dim3(512), 0, st, T, q, (fq*)partials, (long long*)raw);
+    if (raw) hipLaunchKernelGGL(k_reduce_cross_raw, dim3(160), dim3(kThreads), 0, st, (const long long*)raw, (const fq*)partials, (int)gx, red);
+    else hipLaunchKernelGGL(k_reduce_cross, dim3(160), dim3(kThreads), 0, st, (const fq*)partials, (int)gx, 80, red);
     hipLaunchKernelGGL(k_cross64_fix, dim3(1), dim3(128), 0, st, (const fq*)red, qn, (fq*)out);
 }
 // launch_fold3_tables followed by launch_cross64 on its result, as one sweep (needs cross64_fits(outlen / 8)); ring = per-wave DMA slots
 void launch_fold3_cross64(const void* const s[4], void* const d[4], size_t outlen, const uint64_t* r3, const uint64_t two24[4], void* wbuf,
-                          int ring, void* partials, void* out, hipStream_t st, const DmaGates& gates) {
+                          int ring, void* partials, void* raw, void* out, hipStream_t st, const DmaGates& gates) {
     Tab4 S;
     Tab4w D;
     for (int k = 0; k < 4; ++k) { S.t[k] = (const fq*)s[k]; D.t[k] = (fq*)d[k]; }
     const size_t q = outlen / 8;
-    size_t gx = std::min<size_t>(q / 64, 128);
-    const size_t need = (q + ((size_t)1 << 16) - 1) >> 16;
-    if (gx < need) gx = need;
+    const size_t gx = cross64_grid(q);
     fq* red = (fq*)partials + 2 * gx * 80;
     fq qn{};
     qn.v[0] = (u32)q;
@@ -1542,11 +1590,12 @@ void launch_fold3_cross64(const void* const s[4], void* const d[4], size_t outle
         const fq kfix = ZK_MFMA_FOLD_FIX;
         g_forms |= kFormFold3Cross64Mfma;
         const int np = ring == 8 ? 4 : ring - 10;
-#define ZK_F3M(BV, NV) hipLaunchKernelGGL((k_fold3_cross64_mfma<BV, NV>), dim3((unsigned)gx, 2), dim3(256), 0, st, S, D, outlen, (const u32x4*)wbuf, kfix, (fq*)partials)
+#define ZK_F3M(BV, NV) hipLaunchKernelGGL((k_fold3_cross64_mfma<BV, NV>), dim3((unsigned)gx, 2), dim3(256), 0, st, S, D, outlen, (const u32x4*)wbuf, kfix, (fq*)partials, (long long*)raw)
         if (stream_stores) { if (np == 2) ZK_F3M(true, 2); else if (np == 3) ZK_F3M(true, 3); else ZK_F3M(true, 4); }
         else { if (np == 2) ZK_F3M(false, 2); else if (np == 3) ZK_F3M(false, 3); else ZK_F3M(false, 4); }
 #undef ZK_F3M
-        hipLaunchKernelGGL(k_reduce_cross, dim3(160), dim3(kThreads), 0, st, (const fq*)partials, (int)gx, 80, red);
+        if (raw) hipLaunchKernelGGL(k_reduce_cross_raw, dim3(160), dim3(kThreads), 0, st, (const long long*)raw, (const fq*)partials, (int)gx, red);
+        else hipLaunchKernelGGL(k_reduce_cross, dim3(160), dim3(kThreads), 0, st, (const fq*)partials, (int)gx, 80, red);
         hipLaunchKernelGGL(k_cross64_fix, dim3(1), dim3(128), 0, st, (const fq*)red, qn, (fq*)out);
         return;
     }

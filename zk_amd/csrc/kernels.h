@@ -112,7 +112,10 @@ void launch_fold2_tables(const void* const s[4], void* const d[4], size_t outlen
 // degree-2 branch, THREE rounds per pass: out[term * 64 + 8 e + e'] (128 elements) = sum_j F_e[j] G_e'[j] of term (F, G) = (t[2 term],
 // t[2 term + 1]), tables of 8 q entries, entry e of quarter-index j at e q + j; needs cross64_fits(q); ring = 3 or 4 LDS tiles
 bool cross64_fits(size_t q);
-void launch_cross64(const void* const t[4], size_t q, int ring, void* partials, void* out, hipStream_t st);
+// raw (device, cross64_raw_bytes(q) bytes, or null): the sweep leaves each workgroup's 64 cross sums as signed integer digits there and the
+// second stage adds them over the workgroups before the one product per digit; null = every workgroup forms its field elements itself
+size_t cross64_raw_bytes(size_t q);
+void launch_cross64(const void* const t[4], size_t q, int ring, void* partials, void* raw, void* out, hipStream_t st);
 // bind the three top variables of four tables of 8 * outlen entries at r3[0..3) (4 limbs each) into d[] (outlen entries each, a
 // multiple of 64); wbuf (>= 80 u32) and partials (>= 1024 elements) are scratch
 void launch_fold3_tables(const void* const s[4], void* const d[4], size_t outlen, const uint64_t* r3, const uint64_t two24[4], void* wbuf,
@@ -131,9 +134,9 @@ int launch_fold2_sum9(const void* const s[4], void* const d[4], size_t outlen, c
 int launch_fold_sum27(int m, const void* const s[4], void* const d[4], size_t outlen, const uint32_t* w28, void* partials, void* out,
                       hipStream_t st, int host_groups_max, bool pwq);
 // launch_fold3_tables followed by launch_cross64 on d[], in one sweep: the folded tables are not re-read (needs cross64_fits(outlen / 8));
-// ring = LDS-DMA slots per wave (3, 4 or 5)
+// ring = LDS-DMA slots per wave (3, 4 or 5); raw as for launch_cross64 with q = outlen / 8 (used by the matrix-core form of the fold)
 void launch_fold3_cross64(const void* const s[4], void* const d[4], size_t outlen, const uint64_t* r3, const uint64_t two24[4], void* wbuf,
-                          int ring, void* partials, void* out, hipStream_t st, const DmaGates& gates = DmaGates());
+                          int ring, void* partials, void* raw, void* out, hipStream_t st, const DmaGates& gates = DmaGates());
 // out[k*n + i] = t[k][i], k < 4, i < n
 void launch_gather4(const void* const t[4], size_t n, void* out, hipStream_t st);
 // out[(t * L + j) * world + q] = in[(q * ntab + t) * L + j]: the ranks' gathered local tables (rank-major) -> the remaining

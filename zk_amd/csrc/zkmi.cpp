@@ -76,6 +76,7 @@ void zk_ctx_destroy(zk_ctx* c) {
     for (auto& s : c->prof_pending) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
     for (auto& p : c->prof_free) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     if (c->partials) (void)hipFree(c->partials);
+    if (c->cross_raw) (void)hipFree(c->cross_raw);
     if (c->sums_dev) (void)hipFree(c->sums_dev);
     if (c->wide_w) (void)hipFree(c->wide_w);
     if (c->sums_host) (void)hipHostFree(c->sums_host);
@@ -742,6 +743,29 @@ void host_sum2x2_rounds(zk_transcript* tr, std::vector<Fq>& T, size_t len, uint6
 // final_out (optional, 4 elements): every table folded at ALL n challenges (the reference's
 // sum_poly after the last partial_evaluate, prover.rs:139) -- GKR needs W(r_b), W(r_c) from it
 // one round per device pass (k_eval3 / k_fold4_eval3)
+// The raw-digit buffer of the cross-sum sweeps for tables of 8 q entries: grow-only, made on first use (a prove at a size the context
+// has seen allocates nothing).  Null (the sweeps then form their field elements per workgroup) when switched off or when the
+// allocation fails.
+static void* cross_raw_for(zk_ctx* c, size_t q) {
+    if (!c->cross_raw_on) return nullptr;
+    const size_t need = zkk::cross64_raw_bytes(q);
+    if (need > c->cross_raw_cap) {
+        if (c->cross_raw) {
+            (void)hipStreamSynchronize(c->stream); // no queued kernel still writes the old buffer
+            (void)hipFree(c->cross_raw);
+            c->cross_raw = nullptr;
+            c->cross_raw_cap = 0;
+        }
+        if (hipMalloc(&c->cross_raw, need) != hipSuccess) {
+            (void)hipGetLastError();
+            c->cross_raw = nullptr;
+            return nullptr;
+        }
+        c->cross_raw_cap = need;
+    }
+    return c->cross_raw;
+}
+
 static int prove_sum2x2_single(zk_ctx* c, const void* const tables[4], size_t len, zk_transcript* tr, uint64_t* coeffs_out,
                           uint64_t* challenges_out, uint64_t* final_out) {
     const unsigned n = ilog2(len);
@@ -947,7 +971,7 @@ static int prove_sum2x2_pairs(zk_ctx* c, const void* const tables[4], size_t len
         ProfScope ps(c, ZK_K_SUM9, (uint64_t)n * 32 * 4);
         have27 = false;
         if (deg2_triple_ok(c, n)) {
-            zkk::launch_cross64(t, n / 8, c->gates.deg2_triple_ring, c->partials, c->sums_host_dev, c->stream); // 128 cross sums straight into pinned host memory
+            zkk::launch_cross64(t, n / 8, c->gates.deg2_triple_ring, c->partials, cross_raw_for(c, n / 8), c->sums_host_dev, c->stream); // 128 cross sums straight into pinned host memory
             return 3;
         }
         sums_kind = zkk::launch_sum9(t, n / 4, c->two24, c->deg2_lazy_from_log, c->partials, c->sums_host_dev, c->stream, c->gates, true) ? kU : 0;
@@ -1038,7 +1062,7 @@ static int prove_sum2x2_pairs(zk_ctx* c, const void* const tables[4], size_t len
         } else if (cont3) {
             // the next pass serves three rounds too: its cross sums come out of this fold's sweep
             ProfScope ps(c, ZK_K_FOLD2X4_SUM9, (uint64_t)curlen * 32 * 4 + (uint64_t)outlen * 32 * 4);
-            zkk::launch_fold3_cross64(cur, dst, outlen, rs, c->two24, c->wide_w, c->gates.deg2_fold3_fused, c->partials, c->sums_host_dev, c->stream,
+            zkk::launch_fold3_cross64(cur, dst, outlen, rs, c->two24, c->wide_w, c->gates.deg2_fold3_fused, c->partials, cross_raw_for(c, outlen / 8), c->sums_host_dev, c->stream,
                                       c->gates);
         } else if (K == 2 && outlen > kHostTail && fb > 0 && outlen < ((size_t)1 << std::min(fb, 62))) {
             // small tables: the fold and the nine sums of its result in one launch
@@ -1270,7 +1294,7 @@ int zk_shard4_cross64(zk_shard4* s, void* cross_dev_out) {
     if (rc) return rc;
     {
         ProfScope ps(c, ZK_K_SUM9, (uint64_t)s->len * 32 * 4);
-        zkk::launch_cross64(s->cur, s->len / 8, c->gates.deg2_triple_ring, c->partials, cross_dev_out, c->stream);
+        zkk::launch_cross64(s->cur, s->len / 8, c->gates.deg2_triple_ring, c->partials, cross_raw_for(c, s->len / 8), cross_dev_out, c->stream);
     }
     HIPCHK(c, hipGetLastError());
     return ZK_OK;
@@ -1296,7 +1320,7 @@ int zk_shard4_fold3(zk_shard4* s, const uint64_t r3[12], void* next_dev_out, int
     int next = 0;
     if (next_dev_out && c->gates.deg2_fold3_fused && deg2_triple_ok(c, outlen)) {
         ProfScope ps(c, ZK_K_FOLD2X4_SUM9, (uint64_t)s->len * 32 * 4 + (uint64_t)outlen * 32 * 4);
-        zkk::launch_fold3_cross64(s->cur, dst, outlen, r3, c->two24, c->wide_w, c->gates.deg2_fold3_fused, c->partials, next_dev_out, c->stream, c->gates);
+        zkk::launch_fold3_cross64(s->cur, dst, outlen, r3, c->two24, c->wide_w, c->gates.deg2_fold3_fused, c->partials, cross_raw_for(c, outlen / 8), next_dev_out, c->stream, c->gates);
         next = 3;
     } else {
         {
@@ -1305,7 +1329,7 @@ int zk_shard4_fold3(zk_shard4* s, const uint64_t r3[12], void* next_dev_out, int
         }
         if (next_dev_out && deg2_triple_ok(c, outlen)) {
             ProfScope ps(c, ZK_K_SUM9, (uint64_t)outlen * 32 * 4);
-            zkk::launch_cross64(dst, outlen / 8, c->gates.deg2_triple_ring, c->partials, next_dev_out, c->stream);
+            zkk::launch_cross64(dst, outlen / 8, c->gates.deg2_triple_ring, c->partials, cross_raw_for(c, outlen / 8), next_dev_out, c->stream);
             next = 3;
         } else if (next_dev_out && outlen >= 4) {
             ProfScope ps(c, ZK_K_SUM9, (uint64_t)outlen * 32 * 4);
@@ -1466,6 +1490,11 @@ int zk_ctx_set_dma_gates(zk_ctx* c, int sums_from_log, int wide_stream_from_log,
     c->gates.sums_from_log = sums_from_log;
     c->gates.wide_stream_from_log = wide_stream_from_log;
     c->gates.fold2_from_log = fold2_from_log;
+    return ZK_OK;
+}
+int zk_ctx_set_deg2_raw_cross(zk_ctx* c, int on) {
+    if (!c) return ZK_E_ARG;
+    c->cross_raw_on = on != 0;
     return ZK_OK;
 }
 int zk_ctx_set_wide_mfma(zk_ctx* c, int from_log, int workgroups_per_cu, int depth) {

@@ -84,6 +84,9 @@ struct zk_ctx {
     bool gkr_strict_claims = false; // zk_gkr_verify also binds every layer's claim (zk_ctx_set_gkr_strict_claims)
     bool validate_uploads = true;   // zk_mle_upload_mont* reject limbs >= p (zk_ctx_set_validate)
     zk_comm* comm = nullptr;     // zk_comm_init_*: this context is rank `comm->rank` of a sharded prove
+    void* cross_raw = nullptr;   // raw digits of the cross sums (launch_cross64 / launch_fold3_cross64), grow-only, made on first use
+    size_t cross_raw_cap = 0;    // bytes
+    bool cross_raw_on = true;    // zk_ctx_set_deg2_raw_cross
     void* work[2] = {nullptr, nullptr};
     size_t work_cap[2] = {0, 0}; // bytes
     void* stage = nullptr;       // kChunkElems elements
