@@ -1174,7 +1174,16 @@ __global__ void __launch_bounds__(kThreads) k_reduce_cross_raw(const long long* 
     __shared__ long long sh[kThreads / 64][64];
     const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
     long long s = 0;
-    for (int b = slice; b < gx; b += kThreads / 64) s += raw[(((size_t)term * gx + b) * 64 + v) * 64 + lane];
+    const long long* __restrict__ col = raw + ((size_t)term * gx * 64 + v) * 64 + lane; // workgroup b: + b * 4096
+    int b = slice;
+    for (; b + 7 * (kThreads / 64) < gx; b += 8 * (kThreads / 64)) { // eight loads in flight per lane
+        long long x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) x[u] = col[(size_t)(b + u * (kThreads / 64)) * 4096];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += x[u];
+    }
+    for (; b < gx; b += kThreads / 64) s += col[(size_t)b * 4096];
     sh[slice][lane] = s;
     __syncthreads();
     if (slice != 0) return;
