@@ -379,7 +379,7 @@ def apply_knobs(args, ctx):
     if args.deg2_first_triple is not None:
         ctx.set_deg2_first_triple(args.deg2_first_triple[0], args.deg2_first_triple[1])
     if args.deg2_triple_from is not None or args.deg2_triple_ring is not None:
-        ctx.set_deg2_triple(args.deg2_triple_from if args.deg2_triple_from is not None else 21, args.deg2_triple_ring or 4)
+        ctx.set_deg2_triple(args.deg2_triple_from if args.deg2_triple_from is not None else 20, args.deg2_triple_ring or 4)
 
 
 def read_kernels(ctx, names=KERNEL_NAMES):

@@ -406,7 +406,8 @@ int zk_ctx_set_deg2_mfma_sums(zk_ctx *ctx, int from_log);
 /* Degree-2 prover (SumPolynomial branch, sumcheck/src/prover.rs:89-107, :131-139): passes over four tables of at least 2^from_log
  * entries (64 = never; tables of whole 64-entry eighths only) serve THREE rounds each: one sweep forms the 8 x 8 cross sums
  * sum_j F_e[j] G_e'[j] of both terms on the matrix cores, the host runs three rounds on them, one fold binds the three variables.
- * ring = 3 or 4 LDS tiles in the sweep.  An execution schedule: proof bytes do not depend on it. */
+ * ring = 3 or 4 LDS tiles in the sweep.  Default from_log 20; relations of the product + linear shape (zk_sumcheck_prove_prod_plus_linear,
+ * the GKR phases) take these sweeps from 2^(from_log + 1) entries.  An execution schedule: proof bytes do not depend on it. */
 int zk_ctx_set_deg2_triple(zk_ctx *ctx, int from_log, int ring);
 /* Three-round passes whose successor serves three rounds too: the three-variable fold and the next level's cross sums are ONE sweep
  * (the folded rows go to HBM and into the LDS tile of the matrix stage, so the folded tables are not re-read).

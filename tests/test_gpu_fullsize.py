@@ -134,7 +134,7 @@ def test_sum2x2_2pow26_config4_size():
     ctx.forms_used()
     proof1, pts1 = zk_amd.SumcheckProver.generate_proof_for_partial_verify(O.fq1(0), f, zk_amd.Transcript())
     assert "cross64" not in ctx.forms_used()
-    ctx.set_deg2_triple(21, 4)          # back to the library defaults: the context is shared with later tests
+    ctx.set_deg2_triple(20, 4)          # back to the library defaults: the context is shared with later tests
     ctx.set_deg2_fused(20)
     ctx.set_deg2_small_triple(20)
     ctx.set_deg2_first_triple(19, 20)
@@ -173,7 +173,7 @@ def test_sum2x2_2pow24_both_nine_sum_kernels_agree():
     sweep (k_sum16_mfma), and the default schedule (three rounds per pass on the 8 x 8 cross sums of k_cross64_mfma, then fused small
     passes) give the same proof bytes at full size."""
     proofs = []
-    # (lazy_from, mfma_from, triple_from, fused_below); the last: the defaults (three rounds per pass from 2^21, fused small passes)
+    # (lazy_from, mfma_from, triple_from, fused_below); the last: the defaults' schedule at this size (three rounds per pass, fused small passes)
     # the fifth: the defaults with every workgroup of the three-round sweeps forming its own field elements (no raw digits)
     for lazy_from, mfma_from, triple_from, fused_below, raw in ((20, 64, 64, 0, True), (-1, 64, 64, 0, True), (20, 22, 64, 0, True), (18, 22, 21, 20, True),
                                                                   (18, 22, 21, 20, False)):

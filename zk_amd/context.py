@@ -91,7 +91,7 @@ class Context:
         the same for relations F G + H * 1 (the GKR phases), 0 = the GKR prover does not use its product-plus-linear kernels at all."""
         check(lib().zk_ctx_set_deg2_first_triple(self.h, below_log, linear_below_log))
 
-    def set_deg2_triple(self, from_log: int = 21, ring: int = 4):
+    def set_deg2_triple(self, from_log: int = 20, ring: int = 4):
         """Degree-2 prover: passes over tables of >= 2^from_log entries serve three rounds each (8 x 8 cross sums per term on the
         matrix cores + one three-variable fold); 64 = never.  ring = LDS tiles of the sweep (3 or 4).  Defaults = the library's (kernels.h DmaGates)."""
         check(lib().zk_ctx_set_deg2_triple(self.h, from_log, ring))

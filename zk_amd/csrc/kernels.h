@@ -53,9 +53,11 @@ struct DmaGates {
     int wide_mfma_wg_per_cu = 1;   // its grid: workgroups per CU (1 and 2 measure alike; LDS admits two at depth 2)
     int sum9_mfma_from_log = 22;   // nine sums on the matrix cores (k_sum16_mfma) from 2^k quarter-entries (measured break-even); 64 = never
     int wide_mfma_depth = 2;       // its pipeline depth K (2..4): table rows of K steps in flight per wave
-    int deg2_triple_from_log = 21; // degree-2 prover: three rounds per pass (k_cross64_mfma + m = 3 fold) on tables of >= 2^k entries; 64 = never.
+    int deg2_triple_from_log = 20; // degree-2 prover: three rounds per pass (k_cross64_mfma + m = 3 fold) on tables of >= 2^k entries; 64 = never.
                                    // A pass that FOLLOWS a three-round pass (the fused fold + cross sums) keeps the form down to results of
-                                   // 2^(k-1) entries: 4 x 2^26 prove 3.93 -> 3.90 ms, 2^23 0.80 -> 0.78; a FIRST pass at 2^20 loses (GKR layers 10.1 -> 11.3 ms)
+                                   // 2^(k-1) entries.  Relations of the product + linear shape (the GKR phases) take these sweeps one size class
+                                   // later (k + 1): their 27-sum passes move three tables instead of four (GKR layers 10.0 ms at 21, 10.3 at 20).
+                                   // 20 since the raw-digit second stage (21 before): 4 x 2^22 0.526 -> 0.481 ms, 4 x 2^20 0.286 -> 0.273
     int deg2_fused_below_log = 20; // degree-2 prover: fold + nine sums in one kernel (k_fold2_sum9) for folded tables below 2^k entries; 0 = never
     int deg2_sum27_first_below_log = 19; // degree-2 prover: the FIRST pass as 27 sums (k_fold_sum27<0>: three rounds before the first fold) for tables below
                                          // 2^k entries; 0 = never (measured: 4 x 2^18 prove 0.224 -> 0.199 ms, 2^14 0.129 -> 0.122; at 2^20 the nine-sum pass wins)

@@ -967,10 +967,11 @@ static int prove_sum2x2_pairs(zk_ctx* c, const void* const tables[4], size_t len
     int sums_kind = 0;
     bool gathered = false; // the last fold has left the four small tables in the pinned buffer already
     bool have27 = false; // the pinned buffer holds k_fold_sum27's 27 sums (or sums_kind workgroups' shares of them): three rounds
+    const bool pwq = ones3 && c->gates.deg2_pwq_first_below_log > 0; // product + linear relation in its own form (k_fold_sum27<M, true>)
     auto launch_sums = [&](const void* const t[4], size_t n) -> int {
         ProfScope ps(c, ZK_K_SUM9, (uint64_t)n * 32 * 4);
         have27 = false;
-        if (deg2_triple_ok(c, n)) {
+        if (deg2_triple_ok(c, n, pwq)) {
             zkk::launch_cross64(t, n / 8, c->gates.deg2_triple_ring, c->partials, cross_raw_for(c, n / 8), c->sums_host_dev, c->stream); // 128 cross sums straight into pinned host memory
             return 3;
         }
@@ -1003,11 +1004,10 @@ static int prove_sum2x2_pairs(zk_ctx* c, const void* const tables[4], size_t len
             for (int i = 0; i < 9; ++i) S[i] = zkh::load(c->sums_host + 4 * i);
         }
     };
-    const bool pwq = ones3 && c->gates.deg2_pwq_first_below_log > 0;
     int K = 0;
     if (curlen > kHostTail) {
         const int fb0 = pwq ? c->gates.deg2_pwq_first_below_log : c->gates.deg2_sum27_first_below_log;
-        if (fb0 > 0 && curlen < ((size_t)1 << std::min(fb0, 62)) && curlen % 16 == 0 && !deg2_triple_ok(c, curlen)) {
+        if (fb0 > 0 && curlen < ((size_t)1 << std::min(fb0, 62)) && curlen % 16 == 0 && !deg2_triple_ok(c, curlen, pwq)) {
             // the first pass as 27 sums: three rounds before the first fold
             ProfScope ps(c, ZK_K_SUM9, (uint64_t)curlen * 32 * (pwq ? 3 : 4));
             sums_kind = zkk::launch_fold_sum27(0, cur, nullptr, curlen, nullptr, c->partials, c->sums_host_dev, c->stream, kHostSumGroups, pwq);
@@ -1048,8 +1048,8 @@ static int prove_sum2x2_pairs(zk_ctx* c, const void* const tables[4], size_t len
         void* dst[4];
         for (int t = 0; t < 4; ++t) dst[t] = (uint8_t*)c->work[pass & 1] + (size_t)t * outlen * kElem;
         const int fb = c->gates.deg2_fused_below_log, tb = c->gates.deg2_sum27_below_log;
-        const bool cont3 = K == 3 && !have27 && c->gates.deg2_fold3_fused && deg2_triple_cont_ok(c, outlen); // this fold leaves the next cross sums
-        if (tb > 0 && outlen > kHostTail && outlen < ((size_t)1 << std::min(tb, 62)) && !deg2_triple_ok(c, outlen) && !cont3) {
+        const bool cont3 = K == 3 && !have27 && c->gates.deg2_fold3_fused && deg2_triple_cont_ok(c, outlen, pwq); // this fold leaves the next cross sums
+        if (tb > 0 && outlen > kHostTail && outlen < ((size_t)1 << std::min(tb, 62)) && !deg2_triple_ok(c, outlen, pwq) && !cont3) {
             // small tables: the fold of this pass's K variables and the 27 sums that serve the next THREE rounds in one launch
             ProfScope ps(c, ZK_K_FOLD2X4_SUM9, ((uint64_t)curlen * 32 + (uint64_t)outlen * 32) * (pwq ? 3 : 4));
             uint32_t w28[8 * 10];

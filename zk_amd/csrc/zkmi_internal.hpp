@@ -158,14 +158,15 @@ inline unsigned next_batch(const zk_ctx* c, unsigned ell) {
 }
 
 // degree-2 prover: does a pass over four tables of n entries serve three rounds (8 x 8 cross sums per term) rather than two?
-inline bool deg2_triple_ok(const zk_ctx* c, size_t n) {
-    const int tf = c->gates.deg2_triple_from_log;
+// linear: the relation is a product term plus a LINEAR term (prove_sum2x2_dev's ones3): one size class later
+inline bool deg2_triple_ok(const zk_ctx* c, size_t n, bool linear = false) {
+    const int tf = c->gates.deg2_triple_from_log + (linear ? 1 : 0);
     return tf < 63 && n >= 512 && n >= ((size_t)1 << std::max(tf, 0)) && zkk::cross64_fits(n / 8);
 }
 // ... and does the fold that FOLLOWS a three-round pass leave its result's cross sums too (k_fold3_cross64*)?  One size class further
 // down than a first pass: the sweep is already running in that form, and the alternative is four fold launches plus a nine-sum pass
-inline bool deg2_triple_cont_ok(const zk_ctx* c, size_t n) {
-    const int tf = c->gates.deg2_triple_from_log;
+inline bool deg2_triple_cont_ok(const zk_ctx* c, size_t n, bool linear = false) {
+    const int tf = c->gates.deg2_triple_from_log + (linear ? 1 : 0);
     return tf < 63 && n >= 512 && n >= ((size_t)1 << std::max(tf - 1, 0)) && zkk::cross64_fits(n / 8);
 }
 
