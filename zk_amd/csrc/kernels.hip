@@ -241,26 +241,26 @@ __global__ void __launch_bounds__(kThreads) k_multifold_lazy(const fq* __restric
 // pass cost the same ~20 % of the HBM rate whether they are 1/2 or 1/16 of the traffic (tools/mfbench,
 // profiles/r01_mfbench_fold_pass_ablation.txt); only at 1/256 does the pass run at the read-only rate, so the
 // first pass over a large table binds eight variables.  2^m x 10 weight limbs no longer fit in kernel
-// arguments: k_eq_weights28 (one workgroup, m + 1 dependent products) derives them from the m challenges into a
+// arguments: k_eq_weights28 (one workgroup, one product per weight from the host-built half trees) writes them into a
 // small device buffer and the fold reads them with wave-uniform addresses, i.e. as scalar loads into SGPRs --
 // no VGPRs and no LDS for the weights.  The group loop stays rolled (its body is 4 inner products), two
 // elements per load buffer keep the kernel at 4 waves per SIMD (the arithmetic, 1.0 ms of a 1.5 ms pass, only
 // hides under the loads with enough waves: 2 waves/SIMD measured 5.2 TB/s, 4 waves 5.6), and the columns are
 // carried once per loop trip so that they stay below 2^64 however many products are summed.
-// ChalWide, eq_weight_of_thread, eq_weights28_block: kernels_common.hpp
-__global__ void __launch_bounds__(kThreads) k_eq_weights28(ChalWide ch, int m, u32* __restrict__ wout) { eq_weights28_block(ch, m, wout); }
+// EqHalves (the kernel's FIRST argument, read through the kernel-argument segment), eq_weight_of_thread, eq_weights28_block: kernels_common.hpp
+__global__ void __launch_bounds__(kThreads) k_eq_weights28(EqHalves, int m, u32* __restrict__ wout) { eq_weights28_block(m, wout); }
 
 // k_multifold_wide_dma<BIG, D> (the LDS-DMA form of the wide pass; the degree-2 folds use it too): kernels_common.hpp
 
 // The same pass for SMALL outputs (below 2^19 entries: a few waves per CU, time set by each lane's serial chain and by
 // launch latency, tools/wide_g_sweep.sh): every workgroup derives the weights itself into LDS -- no separate
 // k_eq_weights28 launch on the critical path -- and reads them as LDS broadcasts; 4 elements per load buffer.
-__global__ void __launch_bounds__(kThreads) k_multifold_wide_lds(const fq* __restrict__ src, fq* __restrict__ dst, size_t Lout, ChalWide ch, int m,
+__global__ void __launch_bounds__(kThreads) k_multifold_wide_lds(EqHalves, const fq* __restrict__ src, fq* __restrict__ dst, size_t Lout, int m,
                                                               int log_ob, fq* __restrict__ partials) {
     constexpr int G = 4;
     __shared__ u32 wl[(1 << kMaxFoldBatch) * 10];
     const int nb = 1 << m, ng = nb / G; // m >= 3: ng is even
-    eq_weights28_block(ch, m, wl);
+    eq_weights28_block(m, wl);
     __syncthreads();
 
     const unsigned gpb = gridDim.x >> log_ob;
@@ -330,10 +330,10 @@ __global__ void __launch_bounds__(kThreads) k_multifold_wide_lds(const fq* __res
 static constexpr int kMfmaTileWords = 1024; // u32 per b-pair: 4 column tiles x 64 lanes x 4 words
 
 // tiles[((bp * 4 + mt) * 64 + lane) * 4 + u]: word u of lane's fragment of the weight tile (b-pair bp, columns 16 mt .. 16 mt + 15).
-// Every workgroup derives all 2^m weights (m/2 + 1 dependent products) and writes its share of the tiles.
-__global__ void __launch_bounds__(kThreads) k_eq_weights_mfma(ChalWide ch, int m, u32* __restrict__ tiles) {
+// Every workgroup derives all 2^m weights (one product each, from the host-built half trees) and writes its share of the tiles.
+__global__ void __launch_bounds__(kThreads) k_eq_weights_mfma(EqHalves, int m, u32* __restrict__ tiles) {
     __shared__ signed char dig[1 << kMaxFoldBatch][32];
-    const fq w = eq_weight_of_thread(ch, m);
+    const fq w = eq_weight_of_thread(m);
     if ((int)threadIdx.x < (1 << m)) { // signed radix-256 digits: the top byte of a canonical element is <= 0x30, so 32 digits do
         int carry = 0;
 #pragma unroll
@@ -521,10 +521,10 @@ __global__ void __launch_bounds__(kThreads) k_multifold_wide_mfma(const fq* __re
 // sums are carried and added across the wave by a butterfly of shuffles, and a single reduction gives the output.
 // Eight rounds per pass at the latency of one: 2^20 -> 2^12 -> 2^4 in two passes.  Weights per workgroup in LDS as
 // in k_multifold_wide_lds (each lane reads ITS weights: stride-10 addresses, two-way bank conflicts at worst).
-__global__ void __launch_bounds__(kThreads) k_multifold_coop(const fq* __restrict__ src, fq* __restrict__ dst, size_t Lout, ChalWide ch, int m,
+__global__ void __launch_bounds__(kThreads) k_multifold_coop(EqHalves, const fq* __restrict__ src, fq* __restrict__ dst, size_t Lout, int m,
                                                               int log_ob, fq* __restrict__ partials) {
     __shared__ u32 wl[(1 << kMaxFoldBatch) * 10];
-    eq_weights28_block(ch, m, wl);
+    eq_weights28_block(m, wl);
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -732,17 +732,11 @@ __global__ void __launch_bounds__(kThreads) k_mad_probe(u32* __restrict__ out, i
 
 // ---- launchers ---------------------------------------------------------------------------
 void launch_eq_weights28(const uint64_t* r, int m, const uint64_t two24[4], void* wbuf, hipStream_t st) {
-    ChalWide ch;
-    for (int l = 0; l < kMaxFoldBatch; ++l) ch.r[l] = l < m ? to_fq(r + 4 * l) : fq{};
-    ch.two24 = to_fq(two24);
-    hipLaunchKernelGGL(k_eq_weights28, dim3(1), dim3(kThreads), 0, st, ch, m, (u32*)wbuf);
+    hipLaunchKernelGGL(k_eq_weights28, dim3(1), dim3(kThreads), 0, st, make_eq_halves(r, m, two24), m, (u32*)wbuf);
 }
 // the weight tiles of the matrix-core fold (k_eq_weights_mfma) for m challenges into wbuf: 2^(m-1) x kMfmaTileWords u32
 void launch_eq_weights_mfma(const uint64_t* r, int m, const uint64_t two24[4], void* wbuf, hipStream_t st) {
-    ChalWide ch;
-    for (int l = 0; l < kMaxFoldBatch; ++l) ch.r[l] = l < m ? to_fq(r + 4 * l) : fq{};
-    ch.two24 = to_fq(two24);
-    hipLaunchKernelGGL(k_eq_weights_mfma, dim3(1u << (m - 1)), dim3(kThreads), 0, st, ch, m, (u32*)wbuf);
+    hipLaunchKernelGGL(k_eq_weights_mfma, dim3(1u << (m - 1)), dim3(kThreads), 0, st, make_eq_halves(r, m, two24), m, (u32*)wbuf);
 }
 // A pass cut into 2^log_ob output blocks leaves one partial sum per workgroup and a second stage adds the g >> log_ob partials of each
 // block.  When every block has ONE workgroup (the small passes: 2^16 -> 2^8 entries, 2^24 -> 2^16 with 256 blocks ...) its partial IS the
@@ -803,16 +797,14 @@ int launch_multifold_wide(int m, const void* src, void* dst, size_t Lout, const 
                           int lds_below_log, int coop_below_log, int log_ob, void* partials, void* out, hipStream_t st, const DmaGates& gates) {
     const bool stream_stores = gates.wide_stream_from_log < 63 && Lout >= ((size_t)1 << std::max(gates.wide_stream_from_log, 0));
     if (m < 3 || m > kMaxFoldBatch || (Lout >> log_ob) >= ((size_t)1 << 31)) return -1;
-    ChalWide ch;
-    for (int l = 0; l < kMaxFoldBatch; ++l) ch.r[l] = l < m ? to_fq(r + 4 * l) : fq{};
-    ch.two24 = to_fq(two24);
+    const EqHalves ch = make_eq_halves(r, m, two24);
     if (coop_below_log > 0 && m >= 6 && Lout < ((size_t)1 << std::min(coop_below_log, 40))) { // tiny output: one wave per output
         size_t per = ((Lout >> log_ob) + 3) / 4, cap = (size_t)kMaxBlocks >> log_ob;
         if (per > cap) per = cap;
         if (per < 1) per = 1;
         const int g = (int)(per << log_ob);
         g_forms |= kFormCoop;
-        hipLaunchKernelGGL(k_multifold_coop, dim3(g), dim3(kThreads), 0, st, (const fq*)src, (fq*)dst, Lout, ch, m, log_ob, (fq*)sums_target(g, log_ob, partials, out));
+        hipLaunchKernelGGL(k_multifold_coop, dim3(g), dim3(kThreads), 0, st, ch, (const fq*)src, (fq*)dst, Lout, m, log_ob, (fq*)sums_target(g, log_ob, partials, out));
         reduce_groups_unless_single(g, log_ob, partials, out, st);
         return g;
     }
@@ -821,7 +813,7 @@ int launch_multifold_wide(int m, const void* src, void* dst, size_t Lout, const 
     if (!rows || (lds_below_log > 0 && (lds_below_log >= 63 || Lout < ((size_t)1 << lds_below_log)))) {
         int g = grid_blocks(Lout >> log_ob, log_ob);
         g_forms |= kFormWideLds;
-        hipLaunchKernelGGL(k_multifold_wide_lds, dim3(g), dim3(kThreads), 0, st, (const fq*)src, (fq*)dst, Lout, ch, m, log_ob, (fq*)sums_target(g, log_ob, partials, out));
+        hipLaunchKernelGGL(k_multifold_wide_lds, dim3(g), dim3(kThreads), 0, st, ch, (const fq*)src, (fq*)dst, Lout, m, log_ob, (fq*)sums_target(g, log_ob, partials, out));
         reduce_groups_unless_single(g, log_ob, partials, out, st);
         return g;
     }

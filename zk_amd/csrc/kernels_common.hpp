@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include "fq_dev.hpp"
+#include "fq_host.hpp"
 #include "kernels.h"
 
 namespace zkk {
@@ -35,55 +36,32 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 // W.w[b] = eq(r,b) * 2^280 mod p as 10 x 28-bit limbs (made on the host), b < 2^M: kernel-argument weights of the small folds
 template <int M> struct W28 { u32 w[1 << M][10]; };
 
-struct ChalWide {
-    fq r[kMaxFoldBatch];
-    fq two24; // 2^24 in Montgomery form: eq * 2^256 -> eq * 2^280 (fq28_redc divides by 2^280)
-};
-
-// wout[b * 10 + j] = limb j of eq(r, b) * 2^280 mod p, b < 2^m (3 <= m <= 8); challenge l sits on bit m-1-l of b.
-// By one workgroup of kThreads: the trees of the top m/2 and of the remaining variables are built side by side
-// (threads 0-15 and 16-31; level l appends variable l as the new least significant bit; the top tree's root is 2^24,
-// so every weight comes out multiplied by it) and one product per weight joins them: m/2 + 1 dependent products (5 at
-// m = 8) instead of m + 1 -- this chain is on the critical path of every wide and tail pass.
-__device__ __forceinline__ fq chal_pick(const ChalWide& ch, int idx) { // ch.r[idx] without dynamic indexing of kernel arguments
-    fq r = ch.r[0];
+// The eq weights of an m-variable pass (3 <= m <= 8) come from two half trees: eq over the top m/2 challenges (times 2^24: fq28_redc
+// divides by 2^280, not 2^256) and eq over the rest, at most 16 entries each, and ONE product per weight joins them.  The trees are
+// 30 host multiplications (make_eq_halves, ~1 us) and travel as the kernel's FIRST argument; until the end of round 3 every kernel
+// built them itself from the challenges (m/2 dependent products and nine barriers at the head of every wide, tail and weight
+// kernel: ~4 us on the critical path of each).  Same field elements either way.
+struct EqHalves { fq half[2][16]; };
+// entry idx (0..31: half[idx >> 4][idx & 15]) of the EqHalves that is the running kernel's FIRST argument, by a lane-indexed load from
+// the kernel-argument segment (dynamic indexing of a by-value argument itself would be copied through scratch)
+__device__ __forceinline__ fq eq_half_arg(int idx) {
+    typedef const __attribute__((address_space(4))) u32x4* kptr;
+    kptr p = (kptr)__builtin_amdgcn_kernarg_segment_ptr() + 2 * idx;
+    const u32x4 lo = p[0], hi = p[1];
+    fq x;
 #pragma unroll
-    for (int k = 1; k < kMaxFoldBatch; ++k)
-        if (idx == k) r = ch.r[k];
-    return r;
+    for (int k = 0; k < 4; ++k) { x.v[k] = lo[k]; x.v[4 + k] = hi[k]; }
+    return x;
 }
-// thread b < 2^m of the workgroup gets eq(r, b) * 2^280 mod p as a plain integer (8 words, canonical); every thread of the
-// workgroup must call it (barriers inside)
-__device__ __forceinline__ fq eq_weight_of_thread(const ChalWide& ch, int m) {
-    __shared__ fq half[2][16];
-    const int mh = m >> 1, ml = m - mh; // 1 <= mh <= ml <= 4
-    const int t = threadIdx.x & 15, side = (threadIdx.x >> 4) & 1;
-    const bool builder = threadIdx.x < 32;
-    if (builder && t == 0) {
-        const fq one = {FQ_R_LIMBS};
-        half[side][0] = side ? one : ch.two24;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int l = 0; l < 4; ++l) {
-        const bool act = builder && l < (side ? ml : mh) && t < (1 << l);
-        fq v, hi;
-        if (act) {
-            v = half[side][t];
-            hi = fq_mul(v, chal_pick(ch, side ? mh + l : l));
-        }
-        __syncthreads();
-        if (act) {
-            half[side][2 * t + 1] = hi;
-            half[side][2 * t] = fq_sub(v, hi);
-        }
-        __syncthreads();
-    }
-    if ((int)threadIdx.x < (1 << m)) return fq_mul(half[0][threadIdx.x >> ml], half[1][threadIdx.x & ((1 << ml) - 1)]);
+// thread b < 2^m of the workgroup gets eq(r, b) * 2^280 mod p as a plain integer (8 words, canonical); challenge l sits on bit m-1-l of b
+__device__ __forceinline__ fq eq_weight_of_thread(int m) {
+    const int ml = m - (m >> 1);
+    if ((int)threadIdx.x < (1 << m)) return fq_mul(eq_half_arg((int)threadIdx.x >> ml), eq_half_arg(16 + ((int)threadIdx.x & ((1 << ml) - 1))));
     return fq_zero();
 }
-__device__ __forceinline__ void eq_weights28_block(const ChalWide& ch, int m, u32* wout) {
-    const fq w = eq_weight_of_thread(ch, m);
+// wout[b * 10 + j] = limb j of eq(r, b) * 2^280 mod p, b < 2^m, by one workgroup of kThreads
+__device__ __forceinline__ void eq_weights28_block(int m, u32* wout) {
+    const fq w = eq_weight_of_thread(m);
     if ((int)threadIdx.x < (1 << m)) {
         u32 l28[10];
         fq28_unpack(w, l28);
@@ -186,6 +164,26 @@ static inline fq to_fq(const uint64_t r[4]) {
         f.v[2 * i + 1] = (u32)(r[i] >> 32);
     }
     return f;
+}
+// the two half trees of an m-variable pass's eq weights (EqHalves above): r = m challenges (Montgomery, 4 limbs each)
+static inline EqHalves make_eq_halves(const uint64_t* r, int m, const uint64_t two24[4]) {
+    EqHalves h{};
+    const int mh = m >> 1, ml = m - mh; // 1 <= mh <= ml <= 4
+    for (int side = 0; side < 2; ++side) {
+        zkh::Fq t[16];
+        t[0] = side ? zkh::one() : zkh::load(two24);
+        const int nv = side ? ml : mh;
+        for (int l = 0; l < nv; ++l) { // level l appends its variable as the new least significant bit
+            const zkh::Fq x = zkh::load(r + 4 * ((side ? mh : 0) + l));
+            for (int b = (1 << l) - 1; b >= 0; --b) {
+                const zkh::Fq hi = zkh::mul(t[b], x);
+                t[2 * b + 1] = hi;
+                t[2 * b] = zkh::sub(t[b], hi);
+            }
+        }
+        for (int b = 0; b < (1 << nv); ++b) h.half[side][b] = to_fq(t[b].l);
+    }
+    return h;
 }
 
 // grid for a pass whose work is cut into 2^log_ob blocks of Lb entries: a multiple of 2^log_ob
