@@ -693,13 +693,18 @@ def _ones_table(n):
     return np.ascontiguousarray(np.tile(O.fq1(1), (n, 1)))   # Montgomery form of 1
 
 
-@pytest.mark.parametrize("mode", ["default", "all27", "off"])
+@pytest.mark.parametrize("mode", ["default", "all27", "off", "lazy9"])
 @pytest.mark.parametrize("log_n", [0, 1, 3, 6, 7, 8, 9, 10, 11, 12, 13, 14, 16, 18])
 def test_prod_plus_linear_vs_oracle(log_n, mode):
     """zk_sumcheck_prove_prod_plus_linear on {f, g, h} against the oracle's prover on SumPolynomial[Prod[f, g], Prod[h, ones]]:
     same round polynomials, challenges and transcript state.  default: the library's thresholds; all27: every pass above the host
-    tail through k_fold_sum27<M, PWQ> (first pass M = 0, then M = 3); off: the general four-table kernels (the form turned off)."""
+    tail through k_fold_sum27<M, PWQ> (first pass M = 0, then M = 3); off: the general four-table kernels (the form turned off);
+    lazy9: the first pass through k_sum9_lazy<PWQ> (the GKR phases' first sweep: the linear term as additions), then the 27-sum passes."""
     c = zk_amd.Context(0)
+    if mode == "lazy9":
+        c.set_deg2_first_triple(0, 1)     # the product + linear form on, but no table is small enough for a 27-sum FIRST pass
+        c.set_deg2_triple(64, 4)
+        c.set_deg2_lazy_sums(0)           # the unreduced-accumulation nine-sum sweep from 64 quarter-entries
     if mode == "all27":
         c.set_deg2_small_triple(62)
         c.set_deg2_first_triple(0, 62)
@@ -713,7 +718,10 @@ def test_prod_plus_linear_vs_oracle(log_n, mode):
     c.forms_used()
     proof, pts = zk_amd.SumcheckProver.generate_proof_product_plus_linear(O.fq1(5), m[0], m[1], m[2], tr)
     forms = c.forms_used()
-    assert ("pwq" in forms) == (mode != "off" and log_n >= 7), forms
+    if mode == "lazy9":
+        assert log_n < 8 or ("pwq" in forms and "sum9_lazy" in forms and "sum27_first" not in forms), forms
+    else:
+        assert ("pwq" in forms) == (mode != "off" and log_n >= 7), forms
     if mode == "all27" and log_n >= 10:
         assert "sum27_first" in forms and "fold_sum27" in forms and "sum9_lazy" not in forms and "sum9" not in forms, forms
     ocoeffs, och = O.sumcheck_prove_sum([[tabs[0], tabs[1]], [tabs[2], _ones_table(n)]], O.fq1(5), otr)
@@ -723,11 +731,17 @@ def test_prod_plus_linear_vs_oracle(log_n, mode):
         assert np.array_equal(t.get_evaluation_points(), src)      # the factor tables are left unmodified
 
 
+@pytest.mark.parametrize("first", ["27", "lazy9"])
 @pytest.mark.parametrize("fill", ["p-1", "zero", "mixed"])
-def test_prod_plus_linear_extreme_values(fill):
+def test_prod_plus_linear_extreme_values(fill, first):
     c = zk_amd.Context(0)
     c.set_deg2_small_triple(62)
-    c.set_deg2_first_triple(0, 62)
+    if first == "27":
+        c.set_deg2_first_triple(0, 62)
+    else:                                  # first pass: k_sum9_lazy<PWQ> (plain 256-bit sums of up to four entries of p - 1 each)
+        c.set_deg2_first_triple(0, 1)
+        c.set_deg2_triple(64, 4)
+        c.set_deg2_lazy_sums(0)
     n = 1 << 11
     pm1 = np.array([((P - 1) >> (64 * k)) & (2**64 - 1) for k in range(4)], dtype=np.uint64)
     tabs = []

@@ -159,6 +159,10 @@ __device__ __forceinline__ fq lds_elem(const u32x4 (&slot)[2][64], int lane) {
     for (int w = 0; w < 4; ++w) { x.v[w] = lo[w]; x.v[4 + w] = hi[w]; }
     return x;
 }
+// PWQ: the relation is P W + Q * 1 (T.t[0] = P, T.t[1] = W, T.t[2] = Q; the constant-one factor T.t[3] is never read): the workgroups of
+// term 1 stage Q's four rows only and ADD -- U[a][b] of (Q, ones) is |a| |b| times the plain sum of Q[a][b] (a set of one entry counts 1,
+// '+' counts 2) -- so they leave the machine to term 0's products (GKR phases at 2^20 entries: the first sweep of every phase).
+template <bool PWQ>
 __global__ void __launch_bounds__(576) k_sum9_lazy(Tab4 T, size_t q, fq fix24, fq* __restrict__ partials) {
     __shared__ u32x4 sh[3][8][2][64];
     const int term = blockIdx.y, lane = threadIdx.x;
@@ -174,10 +178,14 @@ __global__ void __launch_bounds__(576) k_sum9_lazy(Tab4 T, size_t q, fq fix24, f
     u64 acc[20];
 #pragma unroll
     for (int k = 0; k < 20; ++k) acc[k] = 0;
+    u32 lin[9]; // linear term: the plain sum of this lane's operands, 256 bits + a word of carries
+#pragma unroll
+    for (int k = 0; k < 9; ++k) lin[k] = 0;
     const size_t stride = (size_t)gridDim.x * 64, base0 = (size_t)blockIdx.x * 64;
     const int nt = base0 < q ? (int)((q - base0 + stride - 1) / stride) : 0;
+    const bool linear = PWQ && term == 1; // workgroup-uniform
     auto stage = [&](int t) { // rows 2w, 2w + 1 (= slot w, both halves) for w < 8
-        if (w < 8) {
+        if (w < (linear ? 4 : 8)) {
             const size_t j = base0 + (size_t)t * stride + lane;
             const fq* src = ((w & 4) ? G : F) + (size_t)(w & 3) * q + j;
             u32x4* buf = &sh[t % 3][w][0][0];
@@ -209,6 +217,14 @@ __global__ void __launch_bounds__(576) k_sum9_lazy(Tab4 T, size_t q, fq fix24, f
             }
             return x;
         };
+        if (linear) {
+            const fq x = opnd(0); // < 4p < 2^256
+            u32 c = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) lin[k] = __builtin_addc(lin[k], x.v[k], c, &c);
+            lin[8] += c;
+            continue;
+        }
         u32 lf[10], lg[10];
         fq28_unpack(opnd(0), lf);
         fq28_unpack(opnd(1), lg);
@@ -217,6 +233,19 @@ __global__ void __launch_bounds__(576) k_sum9_lazy(Tab4 T, size_t q, fq fix24, f
             since = 0;
             fq28_carry(acc);
         }
+    }
+    if (linear) {
+        fq lo, hi = fq_zero();
+#pragma unroll
+        for (int k = 0; k < 8; ++k) lo.v[k] = lin[k];
+        hi.v[0] = lin[8];
+        const fq r2 = {FQ_R2_LIMBS};
+        fq sgl = fq_add(fq_reduce_256(lo), fq_mul(hi, r2)); // the sum of the stored (Montgomery) values mod p
+        if (A == 2) sgl = fq_add(sgl, sgl);                   // times the ones factor's plain sum over the same set: 1, 2 or 4
+        if (B == 2) sgl = fq_add(sgl, sgl);
+        const fq rl = fq_wave_sum(sgl);
+        if (lane == 0) fq_store(&partials[((size_t)(term * 3 + B) * gridDim.x + blockIdx.x) * 3 + A], rl);
+        return;
     }
     const fq r = fq_wave_sum(fq_mul(fq28_redc(acc), fix24));
     if (lane == 0) fq_store(&partials[((size_t)(term * 3 + B) * gridDim.x + blockIdx.x) * 3 + A], r);
@@ -1509,7 +1538,7 @@ void launch_fold4(const void* const s[4], void* const d[4], size_t half, const u
     hipLaunchKernelGGL(k_fold4, dim3(grid_for(half)), dim3(kThreads), 0, st, S, D, half, to_fq(r));
 }
 int launch_sum9(const void* const t[4], size_t q, const uint64_t fix24[4], int lazy_from_log, void* partials, void* out, hipStream_t st,
-                const DmaGates& gates, bool allow_u) {
+                const DmaGates& gates, bool allow_u, bool pwq) {
     Tab4 T;
     for (int k = 0; k < 4; ++k) T.t[k] = (const fq*)t[k];
     if (gates.sum9_mfma_from_log < 63 && q % 64 == 0 && q >= ((size_t)1 << std::max(gates.sum9_mfma_from_log, 0)) &&
@@ -1532,10 +1561,16 @@ int launch_sum9(const void* const t[4], size_t q, const uint64_t fix24[4], int l
         size_t gx = (q + 63) / 64;
         // 256 workgroups per term (two per CU): this kernel serves the L2-resident sizes (GKR layers: 2^18 quarter-entries), where fewer,
         // longer-running workgroups beat 1024 short ones (GKR config-5 layers 13.4 -> 12.6 ms, 4 x 2^20 prove 0.389 -> 0.358 ms)
+        // (the same cap for the product + linear form: 512 workgroups per term measured 10.3 instead of 10.0 ms of GKR layers)
         if (gx > 256) gx = 256;
         fq* u = (fq*)partials + (size_t)18 * gx; // nine U sums, behind the partials
         g_forms |= kFormSum9Lazy;
-        hipLaunchKernelGGL(k_sum9_lazy, dim3((unsigned)gx, 2), dim3(64, 9), 0, st, T, q, to_fq(fix24), (fq*)partials);
+        if (pwq) {
+            g_forms |= kFormPwq;
+            hipLaunchKernelGGL(k_sum9_lazy<true>, dim3((unsigned)gx, 2), dim3(64, 9), 0, st, T, q, to_fq(fix24), (fq*)partials);
+        } else {
+            hipLaunchKernelGGL(k_sum9_lazy<false>, dim3((unsigned)gx, 2), dim3(64, 9), 0, st, T, q, to_fq(fix24), (fq*)partials);
+        }
         if (allow_u) { // the caller maps U to the nine sums on the host (a few additions): one launch less on the critical path
             hipLaunchKernelGGL(k_reduce9, dim3(9), dim3(kThreads), 0, st, (const fq*)partials, (int)gx, 1, (fq*)out);
             return 1;

@@ -104,8 +104,9 @@ static constexpr size_t kSum9PartialElems = (size_t)160 * kMaxBlocks9 + 256; // 
 // (lazy_from_log < 0: never)
 // Returns 0 when out holds the nine sums; with allow_u, 1 when it holds the nine U sums of k_sum9_lazy instead (out[3 b + a]; the
 // caller applies k_sum9_from_u's linear maps on the host: one launch less on the critical path of a latency-bound pass)
+// pwq: the relation is t[0] t[1] + t[2] * 1 and the lazy sweep runs its linear term as additions (t[3] is not read)
 int launch_sum9(const void* const t[4], size_t q, const uint64_t fix24[4], int lazy_from_log, void* partials, void* out, hipStream_t st,
-                const DmaGates& gates = DmaGates(), bool allow_u = false);
+                const DmaGates& gates = DmaGates(), bool allow_u = false, bool pwq = false);
 // bind the two top variables of four tables of 4*outlen entries (w28: the 4 eq weights as for launch_multifold_lazy)
 // into d[] (outlen entries each)
 // wbuf (device, >= 40 u32) and partials (>= 1024 elements) are scratch for the large-table form; either may be null (then never used)

@@ -975,7 +975,7 @@ static int prove_sum2x2_pairs(zk_ctx* c, const void* const tables[4], size_t len
             zkk::launch_cross64(t, n / 8, c->gates.deg2_triple_ring, c->partials, cross_raw_for(c, n / 8), c->sums_host_dev, c->stream); // 128 cross sums straight into pinned host memory
             return 3;
         }
-        sums_kind = zkk::launch_sum9(t, n / 4, c->two24, c->deg2_lazy_from_log, c->partials, c->sums_host_dev, c->stream, c->gates, true) ? kU : 0;
+        sums_kind = zkk::launch_sum9(t, n / 4, c->two24, c->deg2_lazy_from_log, c->partials, c->sums_host_dev, c->stream, c->gates, true, pwq) ? kU : 0;
         return 2;
     };
     auto nine_sums = [&](Fq S[9]) {
