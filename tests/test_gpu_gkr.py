@@ -235,6 +235,23 @@ def test_verifier_on_a_wide_circuit():
     assert not GKRVerifier.verify_proof(inputs, circuit, zk_amd.Transcript(), proof)
 
 
+def test_gkr_layers_of_2pow21_gates_long_eq_halves():
+    """2^21 gates per layer: the eq half tables have 10 and 11 variables, one more than the host-built two-variable tables of
+    k_eq_small_pairs take, so every half table of these layers comes from k_eq_small (one factor per variable).  Depth 2;
+    prove -> verify accepts, a tampered coefficient is rejected (no dense oracle at this size)."""
+    from zk_amd.synthetic import gkr_layers
+
+    ctx = zk_amd.default_context()
+    depth, k = 2, 21
+    circuit = Circuit.from_arrays(gkr_layers(depth, k), ctx=ctx)
+    inputs = zk_amd.MultiLinearPolynomial.generate(SEED + 3, 1 << k, ctx=ctx)
+    proof = GKRProver.generate_proof(circuit, zk_amd.Transcript(), inputs)
+    assert len(proof.sumcheck_proofs) == depth and all(p.round_polys.shape == (2 * k, 3, 4) for p in proof.sumcheck_proofs)
+    assert GKRVerifier.verify_proof(inputs, circuit, zk_amd.Transcript(), proof)
+    proof.sumcheck_proofs[1].round_polys[5, 1, 0] ^= 1
+    assert not GKRVerifier.verify_proof(inputs, circuit, zk_amd.Transcript(), proof)
+
+
 def test_gkr_config5_full_size():
     """BASELINE config 5 at its real size: depth 16, 2^20 gates per layer (bench.py's circuit, zk_amd.synthetic.gkr_layers):
     prove -> verify accepts and both transcripts end in the same state (gkr_protocol.rs:126-142, gkr/src/verifier.rs:21-119);

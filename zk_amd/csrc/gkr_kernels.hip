@@ -11,6 +11,7 @@
 // (exact arithmetic), from tables of 2^k_in entries.  All kernels are gathers over small tables
 // (<= a few MiB per layer): latency-, not bandwidth-bound.
 #include "fq_dev.hpp"
+#include "fq_host.hpp"
 #include "gkr_kernels.h"
 
 namespace zkk {
@@ -75,6 +76,41 @@ __global__ void __launch_bounds__(kT) k_eq_small(EqJobs J) {
             }
         }
         fq_store(out + o, b_used ? fq_mul(a, b) : a);
+    }
+}
+
+// The same tables for k <= 2 * kEqPairs variables from host-built TWO-variable tables: pair p covers x[2p], x[2p + 1] (bits k-1-2p and
+// k-2-2p of o; a last pair of an odd k covers x[k-1] alone), its four entries eq((x[2p], x[2p+1]), (b, b')) at index 2b + b' cost the
+// host one product, the scale sits in pair 0, and an entry of the table is a product of ceil(k/2) factors: 4 products per entry instead
+// of 9-10 at k = 10 (the half tables of every GKR layer at 2^20 gates).  The tables are the kernel's FIRST argument and are read through the
+// kernel-argument segment with a lane-dependent index (as eq_half_arg in kernels_common.hpp).  Same field elements as k_eq_small.
+static constexpr int kEqPairs = 5;
+struct EqPairJobs { fq tab[4][kEqPairs][4]; fq* out[4]; int k[4]; };
+__device__ __forceinline__ fq eq_pair_arg(int idx) {
+    typedef const __attribute__((address_space(4))) u32x4* kptr;
+    kptr p = (kptr)__builtin_amdgcn_kernarg_segment_ptr() + 2 * idx;
+    const u32x4 lo = p[0], hi = p[1];
+    fq x;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { x.v[w] = lo[w]; x.v[4 + w] = hi[w]; }
+    return x;
+}
+__global__ void __launch_bounds__(kT) k_eq_small_pairs(EqPairJobs J) {
+    const int job = blockIdx.y, k = J.k[job], np = (k + 1) >> 1;
+    fq* __restrict__ out = J.out[job];
+    const size_t n = (size_t)1 << k, stride = (size_t)gridDim.x * kT;
+    for (size_t o = (size_t)blockIdx.x * kT + threadIdx.x; o < n; o += stride) {
+        fq acc = fq_zero();
+#pragma unroll
+        for (int p = 0; p < kEqPairs; ++p) {
+            if (p < np) {
+                const int sh = k - 2 - 2 * p; // the pair's low bit; -1 for the single variable that ends an odd k
+                const int bits = sh >= 0 ? (int)((o >> sh) & 3) : (int)((o & 1) << 1);
+                const fq f = eq_pair_arg((job * kEqPairs + p) * 4 + bits);
+                acc = p == 0 ? f : fq_mul(acc, f);
+            }
+        }
+        fq_store(out + o, acc);
     }
 }
 
@@ -206,6 +242,37 @@ void launch_circuit_layer(const void* in, void* out, const uint32_t* left, const
     hipLaunchKernelGGL(k_circuit_layer, dim3(grid1d(n_out)), dim3(kT), 0, st, (const fq*)in, (fq*)out, left, right, op, n_gates, n_out);
 }
 void launch_eq_small_multi(int njobs, void* const out[], const int k[], const uint64_t* const x[], const uint64_t* const scale[], hipStream_t st) {
+    bool pairs = njobs >= 1 && njobs <= 4;
+    for (int j = 0; j < njobs && j < 4; ++j) pairs = pairs && k[j] >= 1 && k[j] <= 2 * kEqPairs;
+    if (pairs) { // short halves: two-variable tables from the host, ceil(k/2) - 1 products per entry
+        EqPairJobs J{};
+        int kmax = 0;
+        const zkh::Fq one = zkh::one();
+        for (int j = 0; j < njobs; ++j) {
+            J.out[j] = (fq*)out[j];
+            J.k[j] = k[j];
+            kmax = k[j] > kmax ? k[j] : kmax;
+            const zkh::Fq sc = zkh::load(scale[j]);
+            for (int p = 0; p < (k[j] + 1) / 2; ++p) {
+                zkh::Fq e[4];
+                const zkh::Fq a = zkh::load(x[j] + 4 * (2 * p));
+                if (2 * p + 1 < k[j]) {
+                    const zkh::Fq b = zkh::load(x[j] + 4 * (2 * p + 1)), ab = zkh::mul(a, b);
+                    e[3] = ab;
+                    e[2] = zkh::sub(a, ab);                                   // a (1 - b)
+                    e[1] = zkh::sub(b, ab);                                   // (1 - a) b
+                    e[0] = zkh::sub(zkh::sub(one, a), e[1]);                  // (1 - a)(1 - b) = 1 - a - (b - ab)
+                } else { // the single last variable: index 2 * bit
+                    e[0] = zkh::sub(one, a);
+                    e[2] = a;
+                    e[1] = e[3] = zkh::Fq{{0, 0, 0, 0}};
+                }
+                for (int i = 0; i < 4; ++i) J.tab[j][p][i] = to_fq4((p == 0 ? zkh::mul(e[i], sc) : e[i]).l);
+            }
+        }
+        hipLaunchKernelGGL(k_eq_small_pairs, dim3(grid1d((size_t)1 << kmax), njobs), dim3(kT), 0, st, J);
+        return;
+    }
     EqJobs J{};
     int kmax = 0;
     for (int j = 0; j < njobs && j < 4; ++j) {
